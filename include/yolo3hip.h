@@ -1,0 +1,163 @@
+/* yolo3hip.h -- C-ABI of libyolo3hip.so: the MI355X (gfx950) kernels under the
+ * YOLOv3 inference hot path of viplix3/YOLO.
+ *
+ * The reference has no FFI layer of its own (it is pure Python over TensorFlow
+ * 1.12 ops); each entry point below replaces the TF op call
+ * site(s) cited beside it.  Conventions:
+ *   - plain pointers and ints only; every pointer is a DEVICE pointer unless it
+ *     is a descriptor struct (host) or says "host";
+ *   - the library never allocates or frees device memory and keeps no state
+ *     besides a thread-local error string; the caller owns every buffer;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     re-entrant across streams/devices, and does not synchronise;
+ *   - return 0 on success, <0 on error (Y3_E_*); y3_last_error() describes it.
+ * Activations are NHWC.  dtype codes: Y3_F32 = 0, Y3_BF16 = 1.
+ */
+#ifndef YOLO3HIP_H
+#define YOLO3HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y3_VERSION 100
+
+enum { Y3_F32 = 0, Y3_BF16 = 1 };
+
+enum {
+    Y3_OK = 0,
+    Y3_E_INVALID = -1,     /* bad argument / unsupported shape            */
+    Y3_E_ALIGN = -2,       /* pointer or leading dimension not aligned     */
+    Y3_E_LAUNCH = -3       /* hipLaunch / runtime error                    */
+};
+
+enum {
+    Y3_CONV_LEAKY = 1,     /* leaky-ReLU alpha=0.1 (build_model.py:174-178)                  */
+    Y3_CONV_RESIDUAL = 2,  /* + residual after the activation (shortcut, :218-227)           */
+    Y3_CONV_UPS2X = 4,     /* store each output pixel 2x2 (nearest upsample, :231-239)       */
+    Y3_CONV_OUT_F32 = 8,   /* store fp32 regardless of compute dtype (head tensors)          */
+    Y3_CONV_IN_F32 = 16    /* input is fp32 regardless of compute dtype (first layer image)  */
+};
+
+/* One fused convolution: conv (+folded BN) + bias [+ leaky] [+ residual] [2x upsampled store].
+ * Replaces tf.pad + tf.layers.conv2d + tf.layers.batch_normalization + tf.nn.leaky_relu
+ * (build_model.py:151-178), optionally tf.math.add (:224) and
+ * tf.image.resize_nearest_neighbor (:236); route/concat (:190-193) is expressed through
+ * in_ld/out_ld (a tensor may be a channel slice of a wider buffer).
+ * Padding rule (build_model.py:124,151-154): ksize 3 -> one zero row/col before the
+ * first input row/col, and whatever the window needs after the last (stride 1: SAME;
+ * stride 2: top/left pad then VALID); ksize 1 -> none. */
+typedef struct y3_conv_desc {
+    int32_t dtype;        /* Y3_F32 or Y3_BF16: element type of in/w/res/out and of the MFMA    */
+    int32_t batch;
+    int32_t in_h, in_w, in_c;
+    int32_t in_ld;        /* elements between consecutive pixels of `in`  (>= in_c)             */
+    int32_t out_h, out_w, out_c;
+    int32_t out_ld;       /* elements between consecutive pixels of `out` (>= out_c rounded to 8)*/
+    int32_t res_ld;       /* same for `residual`                                                */
+    int32_t ksize;        /* 1 or 3                                                             */
+    int32_t stride;       /* 1 or 2                                                             */
+    int32_t k_pad;        /* row length of the packed weight matrix, see y3_conv_weight_layout  */
+    int32_t n_pad;        /* rows of the packed weight matrix                                   */
+    int32_t flags;        /* Y3_CONV_*                                                          */
+} y3_conv_desc;
+
+/* Packed weights: w[n][k], n < n_pad, k < k_pad, k = (kh*ksize + kw)*in_c + c, zero filled
+ * beyond out_c / ksize^2*in_c; bias[n_pad] fp32.  The host folds BN.
+ * Given in_c/out_c/ksize/dtype this fills k_pad, n_pad and returns which kernel family
+ * will run (0 = MFMA implicit GEMM, 1 = direct).  Host-only, no GPU needed. */
+int y3_conv_weight_layout(y3_conv_desc *desc);
+
+/* `zeros` is a >=256-byte zero-filled device buffer (source of padding taps). */
+int y3_conv2d_fused(const y3_conv_desc *desc, const void *in, const void *w, const float *bias,
+                    const void *residual, void *out, const void *zeros, void *stream);
+
+/* tf.nn.max_pool(padding='SAME'), build_model.py:207-210.  c % (16/elsize) == 0. */
+int y3_maxpool2d(int dtype, const void *in, void *out, int batch, int in_h, int in_w, int c,
+                 int in_ld, int out_ld, int size, int stride, void *stream);
+
+/* Fallbacks for cfgs the planner cannot fuse: nearest 2x upsample (build_model.py:236),
+ * channel-slice copy for route/concat (:191), residual add (:224). */
+int y3_upsample2x(int dtype, const void *in, void *out, int batch, int in_h, int in_w, int c,
+                  int in_ld, int out_ld, void *stream);
+int y3_copy_channels(int dtype, const void *in, void *out, int64_t pixels, int c,
+                     int in_ld, int out_ld, void *stream);
+int y3_shortcut_add(int dtype, const void *a, const void *b, void *out, int64_t pixels, int c,
+                    int a_ld, int b_ld, int out_ld, void *stream);
+
+/* ---- decode -------------------------------------------------------------------------
+ * Fused get_head + correct_boxes + get_boxes_and_scores + score threshold
+ * (utils/utils.py:43-160, inference.py:124-127) over up to 3 scales.
+ * Per image the pooled box index is p = scale_base + (gy*g + gx)*num_anchors + a with the
+ * scales in the order given (coarse first, inference.py:110-125).
+ * records[b][p] (32 bytes): f32 y_min, x_min, y_max, x_max, score, u32 class bitmask[3]
+ *   score = conf * max_c(prob_c); bit c set iff prob_c >= max (all tied classes,
+ *   utils/utils.py:150-154).  num_classes <= 96.
+ * cand_idx[b][0..cand_count[b]) : pooled indices with score >= score_threshold (any order).
+ * class_count[b][c] : number of those candidates whose bitmask has class c.
+ * cand_count and class_count must be zeroed by the caller before the call. */
+typedef struct y3_decode_desc {
+    int32_t batch;
+    int32_t num_scales;          /* 1..3                                                     */
+    int32_t num_classes;
+    int32_t num_anchors;         /* anchors per scale (3)                                    */
+    int32_t grid_h[3], grid_w[3];
+    int32_t head_ld[3];          /* floats between consecutive cells of head l               */
+    float   anchors[3][3][2];    /* [scale][anchor](w,h), already mask-selected              */
+    float   stride_x[3], stride_y[3];   /* floor(input_w / grid_w), floor(input_h / grid_h)  */
+    float   score_threshold;
+    int32_t boxes_per_image;     /* sum over scales of gh*gw*num_anchors                     */
+} y3_decode_desc;
+
+/* letterbox[b] = {scale, offset_h, offset_w, 0} per image (utils/utils.py:114-116). */
+int y3_decode(const y3_decode_desc *desc, const float *head0, const float *head1, const float *head2,
+              const float *letterbox, float *records, int32_t *cand_idx, int32_t *cand_count,
+              int32_t *class_count, void *stream);
+
+/* Dense forms kept for API parity with the reference's helper functions. */
+/* get_head (utils/utils.py:43-96) for one scale: xy,wh [cells*A*2], conf [cells*A], cls [cells*A*C]. */
+int y3_get_head(const float *head, int batch, int grid_h, int grid_w, int head_ld, int num_anchors,
+                int num_classes, const float *anchors_wh, float stride_x, float stride_y,
+                float *box_xy, float *box_wh, float *conf, float *cls, void *stream);
+/* correct_boxes (utils/utils.py:100-129): n boxes, one letterbox triple. */
+int y3_correct_boxes(const float *box_xy, const float *box_wh, int64_t n, float scale, float off_h,
+                     float off_w, float *boxes, void *stream);
+/* records -> dense boxes [n][4] and box_scores [n][num_classes] (utils/utils.py:148-159). */
+int y3_expand_scores(const float *records, int64_t n, int num_classes, float *boxes, float *box_scores,
+                     void *stream);
+
+/* ---- NMS ----------------------------------------------------------------------------
+ * Per-(image, class) greedy NMS == 80 x tf.image.non_max_suppression (inference.py:136-152):
+ * candidates of class c = cand_idx entries whose record has bit c; visited by descending
+ * score (ties: lower pooled index first); selected iff IoU > iou_threshold with no earlier
+ * selected box; at most max_boxes (<= 256).  Persistent workgroups walk the (image, class)
+ * pairs; the class's candidate list and its alive map are LDS-resident (so
+ * boxes_per_image <= 30720), IoU tests are wave-parallel.
+ * kept_idx[b][c][k]  pooled index of the k-th selected box (k < kept_count[b][c]);
+ * kept_rank (nullable) the same box as an index into the class-masked array (tf nms_index). */
+int y3_nms(const float *records, const int32_t *cand_idx, const int32_t *cand_count,
+           const int32_t *class_count, int batch, int boxes_per_image, int num_classes, int max_boxes,
+           float iou_threshold, int32_t *kept_idx, int32_t *kept_rank, int32_t *kept_count,
+           void *stream);
+/* dynamic LDS the NMS kernel takes for this pool size (host-only helper). */
+int y3_nms_lds_bytes(int boxes_per_image);
+
+/* gather + class-major concat (inference.py:153-167): per image up to num_classes*max_boxes rows.
+ * out_boxes [b][cap][4], out_scores [b][cap], out_classes [b][cap], out_count [b]; cap = num_classes*max_boxes. */
+int y3_pack_outputs(const float *records, const int32_t *kept_idx, const int32_t *kept_count, int batch,
+                    int boxes_per_image, int num_classes, int max_boxes, float *out_boxes,
+                    float *out_scores, int32_t *out_classes, int32_t *out_count, void *stream);
+
+/* fp32 -> bf16 round-to-nearest-even on device (weight/activation staging). */
+int y3_cast_f32_to_bf16(const float *in, void *out, int64_t n, void *stream);
+int y3_cast_bf16_to_f32(const void *in, float *out, int64_t n, void *stream);
+
+int y3_version(void);
+const char *y3_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO3HIP_H */

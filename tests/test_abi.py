@@ -1,0 +1,53 @@
+"""The C-ABI library loads and exports every symbol include/yolo3hip.h declares; host-only
+entry points behave (no GPU compute is attempted here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from yolo_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "yolo3hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(y3_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = _declared()
+    assert "y3_conv2d_fused" in names and "y3_nms" in names and len(names) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libyolo3hip.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+
+
+def test_version_and_layout(lib):
+    assert lib.y3_version() == 100
+    assert _lib.conv_weight_layout(_lib.Y3_BF16, 3, 32, 3, in_f32=True) == (1, 27, 32)
+    assert _lib.conv_weight_layout(_lib.Y3_BF16, 32, 64, 3) == (0, 320, 64)
+    assert _lib.conv_weight_layout(_lib.Y3_BF16, 1024, 255, 1) == (0, 1024, 256)
+    assert _lib.conv_weight_layout(_lib.Y3_F32, 512, 1024, 3) == (0, 4608, 1024)
+    assert _lib.conv_weight_layout(_lib.Y3_F32, 3, 16, 3) == (1, 27, 32)
+    assert lib.y3_nms_lds_bytes(22743) == 22743 * 5 + 16
+
+
+def test_errors_surface_as_exceptions(lib):
+    with pytest.raises(ValueError, match="ksize"):
+        _lib.conv_weight_layout(_lib.Y3_BF16, 32, 64, 5)
+    d = _lib.ConvDesc()
+    rc = lib.y3_conv2d_fused(ctypes.byref(d), None, None, None, None, None, None, None)
+    assert rc == -1 and b"null pointer" in lib.y3_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libyolo3hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,75 @@
+"""CPU tests of the planner (fusion, zero-copy concat, arena liveness) and of the weight
+packing: every plan is interpreted op by op in numpy (tests/plan_sim.py) and must give the
+oracle's head tensors."""
+import numpy as np
+import pytest
+
+import plan_sim
+from oracle import darknet as od
+from yolo_amd import config, planner
+from yolo_amd import darknet_weights as dw
+
+
+def _check(cfg, size, batch, fuse):
+    layers, oi = planner.parse_cfg(cfg, 80)
+    ol, ooi = od.parse_layers(cfg, 80)
+    params = dw.random_params(layers, seed=11)
+    x = np.random.default_rng(1).random((batch, size, size, 3), dtype=np.float32)
+    ref = od.forward(ol, ooi, params, x)
+    plan = planner.build_plan(layers, oi, batch, size, size, "fp32", fuse=fuse)
+    out = plan_sim.Sim(plan, layers, params, x).run()
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4)
+    return plan
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_tiny_plan_matches_oracle(fuse):
+    plan = _check(config.yolov3_tiny_cfg_path, 416, 1, fuse)
+    kinds = [op["kind"] for op in plan.ops]
+    assert kinds.count("conv") == 13 and kinds.count("maxpool") == 6
+    assert kinds.count("upsample") == (0 if fuse else 1) and "copy" not in kinds
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_yolov3_plan_matches_oracle(fuse):
+    plan = _check(config.yolov3_cfg_path, 96, 2, fuse)
+    kinds = [op["kind"] for op in plan.ops]
+    assert kinds.count("conv") == 75 and "copy" not in kinds
+    if fuse:      # all 23 shortcuts, both upsamples and both concats are fused away
+        assert set(kinds) == {"conv"}
+        assert sum(1 for op in plan.ops if op["res"] is not None) == 23
+        assert sum(1 for op in plan.ops if op["ups"]) == 2
+    else:
+        assert kinds.count("add") == 23 and kinds.count("upsample") == 2
+
+
+def test_plan_shapes_and_alignment():
+    layers, oi = planner.parse_cfg(config.yolov3_cfg_path, 80)
+    for dtype, epc in (("bf16", 8), ("fp32", 4)):
+        plan = planner.build_plan(layers, oi, 64, 608, 608, dtype)
+        assert [(h["h"], h["c"], h["ld"]) for h in plan.heads] == [(19, 255, 256), (38, 255, 256), (76, 255, 256)]
+        for op in plan.ops:
+            for k in ("x", "y", "res"):
+                t = op.get(k)
+                if t is None or t["buf"] == "in":
+                    continue
+                assert t["ld"] % epc == 0 and t["off"] % epc == 0
+                if t["buf"][0] == "arena":
+                    assert t["buf"][1] % 256 == 0
+        # route [-1, 61] and [-1, 36] read one buffer: 768 and 384 channels
+        assert sorted(op["x"]["ld"] for op in plan.ops if op["in_c"] in (768, 384)) == [384, 768]
+        assert plan.arena_bytes < 8 * 2 ** 30
+
+
+def test_layer_walk_quirks():
+    layers, oi = planner.parse_cfg(config.yolov3_tiny_cfg_path, 80)
+    assert oi == [15, 22] and len(layers) == 24
+    assert layers[17] == dict(type="route", ids=[13]) and layers[20]["ids"] == [19, 8]
+    assert layers[15]["filters"] == 255 and layers[15]["head"]
+    layers5, _ = planner.parse_cfg(config.yolov3_tiny_cfg_path, 5)
+    assert layers5[15]["filters"] == 30 and layers5[22]["filters"] == 30     # build_model.py:156-159
+    shapes = planner.infer_shapes(layers, 416, 416)
+    assert shapes[11] == (13, 13, 512) and shapes[10] == (13, 13, 512)       # maxpool size 2 stride 1, SAME
+    assert shapes[20] == (26, 26, 384)

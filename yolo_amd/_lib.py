@@ -1,0 +1,89 @@
+"""ctypes face of libyolo3hip.so (include/yolo3hip.h).  There is no fallback: if the
+HIP library is missing or a call fails, the caller gets an exception."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo3hip.so")
+
+Y3_F32, Y3_BF16 = 0, 1
+CONV_LEAKY, CONV_RESIDUAL, CONV_UPS2X, CONV_OUT_F32, CONV_IN_F32 = 1, 2, 4, 8, 16
+
+c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "dtype", "batch", "in_h", "in_w", "in_c", "in_ld", "out_h", "out_w", "out_c", "out_ld", "res_ld",
+        "ksize", "stride", "k_pad", "n_pad", "flags")]
+
+
+class DecodeDesc(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("num_scales", ctypes.c_int32), ("num_classes", ctypes.c_int32),
+                ("num_anchors", ctypes.c_int32), ("grid_h", ctypes.c_int32 * 3), ("grid_w", ctypes.c_int32 * 3),
+                ("head_ld", ctypes.c_int32 * 3), ("anchors", ((c_f32 * 2) * 3) * 3),
+                ("stride_x", c_f32 * 3), ("stride_y", c_f32 * 3), ("score_threshold", c_f32),
+                ("boxes_per_image", ctypes.c_int32)]
+
+
+# every symbol include/yolo3hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "y3_conv_weight_layout": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "y3_conv2d_fused": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_maxpool2d": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "y3_upsample2x": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "y3_copy_channels": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
+    "y3_shortcut_add": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp]),
+    "y3_decode": (c_int, [ctypes.POINTER(DecodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_get_head": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32, c_f32,
+                            c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_correct_boxes": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp]),
+    "y3_expand_scores": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "y3_nms": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "y3_nms_lds_bytes": (c_int, [c_int]),
+    "y3_pack_outputs": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_cast_f32_to_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "y3_cast_bf16_to_f32": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "y3_version": (c_int, []),
+    "y3_last_error": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise (never fall back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C yolo_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class Y3Error(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().y3_last_error().decode("utf-8", "replace")
+        if rc in (-1, -2):
+            raise ValueError("yolo3hip: %s" % msg)         # bad argument / alignment
+        raise Y3Error("yolo3hip (code %d): %s" % (rc, msg))
+
+
+def conv_weight_layout(dtype, in_c, out_c, ksize, in_f32=False):
+    """(family, k_pad, n_pad) for a conv; host-only, needs no GPU."""
+    d = ConvDesc()
+    d.dtype, d.in_c, d.out_c, d.ksize = dtype, in_c, out_c, ksize
+    d.flags = CONV_IN_F32 if in_f32 else 0
+    fam = load().y3_conv_weight_layout(ctypes.byref(d))
+    if fam < 0:
+        check(fam)
+    return fam, d.k_pad, d.n_pad

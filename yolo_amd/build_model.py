@@ -1,0 +1,280 @@
+"""Darknet cfg -> network, and the Darknet weight loader: the MI355X counterpart of the
+reference's build_model.py (same public names and argument order):
+
+    unique_config_sections(cfg_file)                                  build_model.py:12
+    yolo(input_images, is_training, config_path, num_classes)         build_model.py:36
+    load_weights(var_list, weights_file)                              build_model.py:273
+
+The reference returns lazy TF tensors that `sess.run` evaluates (inference.py:277).
+Here `yolo()` returns `OutputNodes`: a list-like of lazy head nodes bound to a `Network`;
+calling it (`nodes(images)` / `nodes.run(images)`) launches the fused HIP plan and yields
+the head tensors [B, g, g, 3*(num_classes+5)] (fp32, coarse -> fine), exactly the tensors
+the reference's `yolo()` hands to `predict()`.
+
+torch is used for device memory and streams only; all arithmetic is in libyolo3hip.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, config, planner
+from . import darknet_weights as dw
+from .planner import unique_config_sections  # noqa: F401  (re-exported: reference API)
+
+_NETWORKS = []          # what tf.global_variables() is to the reference's load_weights call
+
+
+def global_variables():
+    """Stand-in for tf.global_variables() in `load_weights(tf.global_variables(), path)`
+    (inference.py:255): the networks built so far."""
+    return list(_NETWORKS)
+
+
+def _dtype_code(dtype):
+    return _lib.Y3_BF16 if dtype == "bf16" else _lib.Y3_F32
+
+
+class _CompiledPlan(object):
+    """A planner.Plan bound to device memory: an arena, and one prepared launcher per op."""
+
+    def __init__(self, net, plan):
+        self.plan = plan
+        self.arena = torch.empty(max(plan.arena_bytes, 256), dtype=torch.uint8, device=net.device)
+        self.launchers = [self._prepare(net, op) for op in plan.ops]
+
+    def _ptr(self, ref, es):
+        """-> (kind, base_offset_bytes)"""
+        buf = ref["buf"]
+        if buf == "in":
+            return ("in", ref["off"] * 4)
+        if buf[0] == "arena":
+            return ("arena", buf[1] + ref["off"] * es)
+        return (buf, ref["off"] * 4)             # ('head', k), fp32
+
+    def _prepare(self, net, op):
+        lib = _lib.load()
+        plan = self.plan
+        es = 2 if plan.dtype == "bf16" else 4
+        code = _dtype_code(plan.dtype)
+        arena_base = self.arena.data_ptr()
+        B = plan.batch
+
+        def resolver(ref, esize=es):
+            kind, off = self._ptr(ref, esize)
+            if kind == "arena":
+                p = arena_base + off
+                return lambda env: p
+            if kind == "in":
+                return lambda env: env["in"] + off
+            k = kind[1]
+            return lambda env: env["heads"][k] + off
+
+        kind = op["kind"]
+        if kind == "conv":
+            w, bias, fam, k_pad, n_pad = net._packed[op["layer"]]
+            d = _lib.ConvDesc()
+            d.dtype, d.batch = code, B
+            d.in_h, d.in_w = op["in_hw"]
+            d.in_c, d.in_ld = op["in_c"], op["x"]["ld"]
+            d.out_h, d.out_w = op["out_hw"]
+            d.out_c, d.out_ld = op["out_c"], op["y"]["ld"]
+            d.res_ld = op["res"]["ld"] if op["res"] is not None else 0
+            d.ksize, d.stride, d.k_pad, d.n_pad = op["ksize"], op["stride"], k_pad, n_pad
+            flags = 0
+            if op["leaky"]: flags |= _lib.CONV_LEAKY
+            if op["res"] is not None: flags |= _lib.CONV_RESIDUAL
+            if op["ups"]: flags |= _lib.CONV_UPS2X
+            if op["out_f32"]: flags |= _lib.CONV_OUT_F32
+            if op["in_f32"]: flags |= _lib.CONV_IN_F32
+            d.flags = flags
+            dref = ctypes.byref(d)
+            x = resolver(op["x"], 4 if op["in_f32"] else es)
+            y = resolver(op["y"], 4 if op["out_f32"] else es)
+            r = resolver(op["res"]) if op["res"] is not None else (lambda env: None)
+            wp, bp, zp = w.data_ptr(), bias.data_ptr(), net._zeros.data_ptr()
+            fn = lib.y3_conv2d_fused
+
+            def launch(env, _keep=(d, w, bias)):
+                return fn(dref, x(env), wp, bp, r(env), y(env), zp, env["stream"])
+            return launch
+        if kind == "maxpool":
+            x, y = resolver(op["x"]), resolver(op["y"])
+            h, w_ = op["in_hw"]
+            args = (B, h, w_, op["c"], op["x"]["ld"], op["y"]["ld"], op["size"], op["stride"])
+            return lambda env: lib.y3_maxpool2d(code, x(env), y(env), *args, env["stream"])
+        if kind == "upsample":
+            x, y = resolver(op["x"]), resolver(op["y"])
+            h, w_ = op["in_hw"]
+            args = (B, h, w_, op["c"], op["x"]["ld"], op["y"]["ld"])
+            return lambda env: lib.y3_upsample2x(code, x(env), y(env), *args, env["stream"])
+        if kind == "copy":
+            x, y = resolver(op["x"]), resolver(op["y"])
+            args = (op["pixels"], op["c"], op["x"]["ld"], op["y"]["ld"])
+            return lambda env: lib.y3_copy_channels(code, x(env), y(env), *args, env["stream"])
+        if kind == "add":
+            a, b, y = resolver(op["a"]), resolver(op["b"]), resolver(op["y"])
+            args = (op["pixels"], op["c"], op["a"]["ld"], op["b"]["ld"], op["y"]["ld"])
+            return lambda env: lib.y3_shortcut_add(code, a(env), b(env), y(env), *args, env["stream"])
+        raise ValueError("unknown op kind %r" % kind)
+
+
+class Network(object):
+    """The compiled detector: cfg layers + packed device weights + cached launch plans."""
+
+    def __init__(self, config_path, num_classes, dtype=None, device=None, fuse=True):
+        self.config_path = config_path
+        self.num_classes = num_classes
+        self.dtype = dtype or config.compute_dtype
+        if self.dtype not in ("bf16", "fp32"):
+            raise ValueError("dtype must be 'bf16' or 'fp32'")
+        self.fuse = fuse
+        self.layers, self.out_index = planner.parse_cfg(config_path, num_classes, config.num_anchors_per_scale)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.params = None
+        self._packed = None
+        self._plans = {}
+        self._zeros = None
+        _lib.load()                 # fail now, loudly, if the HIP library is not built
+
+    # ---- weights ---------------------------------------------------------------------------
+    def set_params(self, params):
+        """params: {layer: {'kernel' HWIO, 'gamma','beta','mean','var' | 'bias'}} (fp32 numpy)."""
+        code = _dtype_code(self.dtype)
+        packed = {}
+        first_conv = next(i for i, L in enumerate(self.layers) if L["type"] == "conv")
+        for li, L in enumerate(self.layers):
+            if L["type"] != "conv":
+                continue
+            kernel, bias = dw.fold_batch_norm(params[li])
+            kh, kw, ci, co = kernel.shape
+            assert (kh, ci, co) == (L["size"], L["cin"], L["filters"]), "layer %d: kernel shape %r" % (li, kernel.shape)
+            fam, k_pad, n_pad = _lib.conv_weight_layout(code, ci, co, kh, in_f32=(li == first_conv))
+            bias_p = np.zeros(n_pad, dtype=np.float32)
+            bias_p[:co] = bias
+            if fam == 0:      # implicit GEMM: [n_pad][k_pad], k = (kh*ks + kw)*Cin + c
+                wp = np.zeros((n_pad, k_pad), dtype=np.float32)
+                wp[:co, :kh * kw * ci] = np.transpose(kernel, (3, 0, 1, 2)).reshape(co, -1)
+                wt = torch.from_numpy(wp)
+                if self.dtype == "bf16":
+                    wt = wt.to(torch.bfloat16)
+            else:             # direct: fp32 [k][n_pad]
+                wp = np.zeros((kh * kw * ci, n_pad), dtype=np.float32)
+                wp[:, :co] = kernel.reshape(-1, co)
+                wt = torch.from_numpy(wp)
+            packed[li] = (wt.to(self.device).contiguous(), torch.from_numpy(bias_p).to(self.device), fam, k_pad, n_pad)
+        self.params = params
+        self._packed = packed
+        self._zeros = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        self._plans = {}
+
+    def load_weights(self, weights_file):
+        self.set_params(dw.read_weights(weights_file, self.layers))
+
+    # ---- execution -------------------------------------------------------------------------
+    def plan_for(self, batch, height, width):
+        key = (batch, height, width)
+        cp = self._plans.get(key)
+        if cp is None:
+            if self._packed is None:
+                raise RuntimeError("weights are not loaded: call load_weights(net, path) first")
+            plan = planner.build_plan(self.layers, self.out_index, batch, height, width, self.dtype, fuse=self.fuse)
+            cp = _CompiledPlan(self, plan)
+            self._plans[key] = cp
+        return cp
+
+    def forward(self, images, chunk=None):
+        """images: float32 NHWC [B,H,W,3] on this network's device, values as the reference
+        feeds them (image/255, inference.py:242).  Returns the head tensors (fp32,
+        [B,g,g,3*(C+5)] views, coarse -> fine).  `chunk` splits the batch into sub-batches
+        that run back to back through the whole plan."""
+        if not isinstance(images, torch.Tensor):
+            images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+        if images.dim() != 4 or images.shape[-1] != 3:
+            raise ValueError("images must be NHWC [B,H,W,3], got %r" % (tuple(images.shape),))
+        images = images.to(device=self.device, dtype=torch.float32).contiguous()
+        B, H, W, _ = images.shape
+        step = B if not chunk else max(1, min(int(chunk), B))
+        first = self.plan_for(step, H, W)
+        heads = [torch.empty((B, hd["h"], hd["w"], hd["ld"]), dtype=torch.float32, device=self.device)
+                 for hd in first.plan.heads]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        in_base = images.data_ptr()
+        for b0 in range(0, B, step):
+            nb = min(step, B - b0)
+            cp = first if nb == step else self.plan_for(nb, H, W)
+            env = {"in": in_base + b0 * H * W * 3 * 4, "stream": stream,
+                   "heads": [h.data_ptr() + b0 * h.stride(0) * 4 for h in heads]}
+            for launch in cp.launchers:
+                rc = launch(env)
+                if rc:
+                    _lib.check(rc)
+        self._keepalive = images
+        return [h[..., :hd["c"]] for h, hd in zip(heads, first.plan.heads)]
+
+    __call__ = forward
+
+
+class HeadNode(object):
+    """Lazy stand-in for one output tensor of the reference's yolo()."""
+
+    def __init__(self, net, index):
+        self.net, self.index = net, index
+
+    def __repr__(self):
+        return "<HeadNode scale_%d of %s>" % (self.index + 1, self.net.config_path)
+
+
+class OutputNodes(list):
+    """What yolo() returns: list of lazy head nodes; call it to evaluate them."""
+
+    def __init__(self, net):
+        super(OutputNodes, self).__init__(HeadNode(net, k) for k in range(len(net.out_index)))
+        self.net = net
+
+    def run(self, images, chunk=None):
+        return self.net.forward(images, chunk=chunk)
+
+    __call__ = run
+
+
+def yolo(input_images, is_training, config_path, num_classes, dtype=None, device=None):
+    """Builds the network described by a Darknet cfg (reference build_model.py:36-270).
+    input_images is accepted for signature parity and may be None (the reference passes a
+    placeholder); is_training must be False (inference path only)."""
+    if is_training:
+        raise ValueError("yolo_amd implements the inference path only: is_training must be False")
+    net = Network(config_path, num_classes, dtype=dtype, device=device)
+    _NETWORKS.append(net)
+    return OutputNodes(net)
+
+
+class _LoadOp(object):
+    """The reference returns tf.assign ops for sess.run; here the load has already happened."""
+
+    def __init__(self, net, path):
+        self.net, self.path = net, path
+
+    def run(self):
+        return None
+
+
+def load_weights(var_list, weights_file):
+    """Loads a Darknet .weights file (reference build_model.py:273-339).  var_list may be a
+    Network, the OutputNodes of yolo(), or global_variables().  A missing file raises
+    FileNotFoundError: nothing is fetched from the network (the reference shells out to wget)."""
+    if isinstance(var_list, Network):
+        nets = [var_list]
+    elif isinstance(var_list, OutputNodes):
+        nets = [var_list.net]
+    else:
+        nets = [v.net if isinstance(v, (OutputNodes, HeadNode)) else v for v in var_list]
+    if not nets:
+        raise ValueError("load_weights: no network to load into")
+    ops = []
+    for net in nets:
+        print("loading weights from {} ...............".format(weights_file))
+        net.load_weights(weights_file)
+        ops.append(_LoadOp(net, weights_file))
+    print("weights loaded successfully!!")
+    return ops

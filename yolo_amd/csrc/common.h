@@ -1,0 +1,38 @@
+// Shared helpers for the gfx950 kernels of libyolo3hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/yolo3hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;      // one 16-byte chunk of bf16
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+void y3_set_error(const char *fmt, ...);
+int y3_check_launch(const char *what);
+
+#define Y3_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            y3_set_error(__VA_ARGS__);         \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+// bf16 <-> f32, round-to-nearest-even; NaN stays NaN via the compiler's cvt (plain cast).
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+    return __uint_as_float(((unsigned int)h) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;                       // hipcc -O3: v_cvt_pk_bf16_f32 (RNE, NaN preserved)
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float leaky01(float x) { return x > 0.0f ? x : 0.1f * x; }
+
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }

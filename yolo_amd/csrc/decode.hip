@@ -1,0 +1,247 @@
+// YOLO head decode for gfx950: get_head + correct_boxes + get_boxes_and_scores + the
+// score threshold of predict(), fused over all scales in one launch.
+//   reference utils/utils.py:43-96, 100-129, 132-160; inference.py:110-127.
+// Bandwidth-bound: the head tensors are read exactly once, 16 lanes per box so that a
+// box's 85 consecutive floats are read as coalesced 64-byte segments; each box leaves
+// one 32-byte record {ymin,xmin,ymax,xmax,score,classmask[3]}.  Boxes whose score
+// passes the threshold are appended to a per-image candidate list (block-aggregated:
+// one atomic per block) and counted per class (LDS histogram) for the NMS kernel.
+// fp32 throughout, no multiply-add contraction (the file is built with
+// -ffp-contract=off), IEEE division, operation order as in the reference.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 1024;      // boxes per block
+constexpr int kMaxClasses = 96;   // 3 x 32-bit class mask
+
+struct DecodeArgs {
+    y3_decode_desc d;
+    const float *head[3];
+    const float *letterbox;
+    float *records;
+    int *cand_idx, *cand_count, *class_count;
+    int scale_base[4];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a) {
+    __shared__ int s_list[kChunk];
+    __shared__ int s_hist[kMaxClasses];
+    __shared__ int s_n, s_base;
+
+    const int b = blockIdx.y;
+    const int N = a.d.boxes_per_image;
+    const int C = a.d.num_classes, A = a.d.num_anchors;
+    const int tid = threadIdx.x;
+    const int j = tid & 15;            // lane within the 16-lane box group
+    const int grp = tid >> 4;          // 16 groups per block
+    if (tid < kMaxClasses) s_hist[tid] = 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+
+    const float scale = a.letterbox[b * 4 + 0];
+    const float off_h = a.letterbox[b * 4 + 1];
+    const float off_w = a.letterbox[b * 4 + 2];
+    const float thr = a.d.score_threshold;
+    const int p_begin = blockIdx.x * kChunk;
+    const int p_end = min(p_begin + kChunk, N);
+
+    for (int pb = p_begin; pb < p_end; pb += 16) {
+        const int p = pb + grp;
+        const bool live = p < p_end;
+        const int pp = live ? p : p_end - 1;                  // keep all lanes in the shuffles
+        const int l = pp >= a.scale_base[2] ? 2 : (pp >= a.scale_base[1] ? 1 : 0);
+        const int q = pp - a.scale_base[l];
+        const int cell = q / A, an = q - cell * A;
+        const int gw = a.d.grid_w[l];
+        const int gy = cell / gw, gx = cell - gy * gw;
+        const float *t = a.head[l] + ((long)b * a.d.grid_h[l] * gw + cell) * a.d.head_ld[l] + an * (5 + C);
+
+        const float tb = j < 5 ? t[j] : 0.0f;                 // lanes 0..4: tx,ty,tw,th,tobj
+        float pc[6];
+        float pmax = -1.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = j + 16 * i;
+            pc[i] = -1.0f;
+            if (c < C) { pc[i] = sigmoidf_(t[5 + c]); pmax = fmaxf(pmax, pc[i]); }    // utils.py:87
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, o, 16));  // utils.py:150
+        unsigned m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = j + 16 * i;
+            if (c < C && pc[i] >= pmax) {                                              // utils.py:151
+                if (i < 2) m0 |= 1u << c; else if (i < 4) m1 |= 1u << (c - 32); else m2 |= 1u << (c - 64);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+            m0 |= __shfl_xor(m0, o, 16); m1 |= __shfl_xor(m1, o, 16); m2 |= __shfl_xor(m2, o, 16);
+        }
+        const float tx = __shfl(tb, 0, 16), ty = __shfl(tb, 1, 16), tw = __shfl(tb, 2, 16);
+        const float th = __shfl(tb, 3, 16), to = __shfl(tb, 4, 16);
+
+        // utils.py:84-92
+        const float bx = (sigmoidf_(tx) + (float)gx) * a.d.stride_x[l];
+        const float by = (sigmoidf_(ty) + (float)gy) * a.d.stride_y[l];
+        const float bw = expf(tw) * a.d.anchors[l][an][0];
+        const float bh = expf(th) * a.d.anchors[l][an][1];
+        const float conf = sigmoidf_(to);
+        // utils.py:118-126
+        const float hw = bw / 2.0f, hh = bh / 2.0f;
+        const float ymin = ((by - hh) - off_h / 2.0f) / scale;
+        const float xmin = ((bx - hw) - off_w / 2.0f) / scale;
+        const float ymax = ((by + hh) - off_h / 2.0f) / scale;
+        const float xmax = ((bx + hw) - off_w / 2.0f) / scale;
+        const float score = conf * (pmax * 1.0f);                                      // utils.py:153-154
+
+        if (live) {
+            float v;
+            switch (j) {
+                case 0: v = ymin; break;
+                case 1: v = xmin; break;
+                case 2: v = ymax; break;
+                case 3: v = xmax; break;
+                case 4: v = score; break;
+                case 5: v = __uint_as_float(m0); break;
+                case 6: v = __uint_as_float(m1); break;
+                default: v = __uint_as_float(m2); break;
+            }
+            if (j < 8) a.records[((long)b * N + p) * 8 + j] = v;
+            if (j == 0 && score >= thr) {                                              // inference.py:127
+                s_list[atomicAdd(&s_n, 1)] = p;
+                unsigned mm[3] = {m0, m1, m2};
+                for (int w = 0; w < 3; ++w)
+                    while (mm[w]) { const int bit = __ffs(mm[w]) - 1; mm[w] &= mm[w] - 1; atomicAdd(&s_hist[w * 32 + bit], 1); }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (tid == 0) s_base = n ? atomicAdd(&a.cand_count[b], n) : 0;
+    if (tid < C && s_hist[tid]) atomicAdd(&a.class_count[b * C + tid], s_hist[tid]);
+    __syncthreads();
+    const int base = s_base;
+    for (int i = tid; i < n; i += kThreads) a.cand_idx[(long)b * N + base + i] = s_list[i];
+}
+
+// Dense forms (API parity with the reference helpers; not on the fused hot path).
+__global__ __launch_bounds__(kThreads) void get_head_kernel(const float *head, long total, int gh, int gw, int ld, int A,
+                                                            int C, const float *anchors, float sx, float sy,
+                                                            float *xy, float *wh, float *conf, float *cls) {
+    const int E = 5 + C;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const int k = (int)(i % E);
+        const long box = i / E;
+        const int an = (int)(box % A);
+        const long cellb = box / A;                  // b*gh*gw + cell
+        const int cell = (int)(cellb % ((long)gh * gw));
+        const int gy = cell / gw, gx = cell - gy * gw;
+        const float t = head[cellb * ld + an * E + k];
+        if (k == 0) xy[box * 2] = (sigmoidf_(t) + (float)gx) * sx;
+        else if (k == 1) xy[box * 2 + 1] = (sigmoidf_(t) + (float)gy) * sy;
+        else if (k < 4) wh[box * 2 + (k - 2)] = expf(t) * anchors[an * 2 + (k - 2)];
+        else if (k == 4) conf[box] = sigmoidf_(t);
+        else cls[box * C + (k - 5)] = sigmoidf_(t);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void correct_boxes_kernel(const float *xy, const float *wh, long n, float scale,
+                                                                 float off_h, float off_w, float *boxes) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        const float bx = xy[i * 2], by = xy[i * 2 + 1];
+        const float hw = wh[i * 2] / 2.0f, hh = wh[i * 2 + 1] / 2.0f;
+        boxes[i * 4 + 0] = ((by - hh) - off_h / 2.0f) / scale;
+        boxes[i * 4 + 1] = ((bx - hw) - off_w / 2.0f) / scale;
+        boxes[i * 4 + 2] = ((by + hh) - off_h / 2.0f) / scale;
+        boxes[i * 4 + 3] = ((bx + hw) - off_w / 2.0f) / scale;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void expand_scores_kernel(const float *rec, long n, int C, float *boxes, float *scores) {
+    const long total = n * C;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const int c = (int)(i % C);
+        const long box = i / C;
+        const float *r = rec + box * 8;
+        const unsigned m = __float_as_uint(r[5 + (c >> 5)]);
+        scores[i] = ((m >> (c & 31)) & 1u) ? r[4] : 0.0f;
+        if (c < 4) boxes[box * 4 + c] = r[c];
+    }
+}
+
+inline unsigned grid_for(long work) {
+    long b = (work + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    return (unsigned)(b > 2048 ? 2048 : b);
+}
+
+}  // namespace
+
+extern "C" int y3_decode(const y3_decode_desc *d, const float *head0, const float *head1, const float *head2,
+                         const float *letterbox, float *records, int32_t *cand_idx, int32_t *cand_count,
+                         int32_t *class_count, void *stream) {
+    Y3_REQUIRE(d && head0 && letterbox && records && cand_idx && cand_count && class_count, Y3_E_INVALID, "decode: null pointer");
+    Y3_REQUIRE(d->num_scales >= 1 && d->num_scales <= 3, Y3_E_INVALID, "decode: %d scales", d->num_scales);
+    Y3_REQUIRE(d->num_classes >= 1 && d->num_classes <= kMaxClasses, Y3_E_INVALID, "decode: %d classes (max %d)", d->num_classes, kMaxClasses);
+    Y3_REQUIRE(d->num_anchors >= 1 && d->num_anchors <= 3, Y3_E_INVALID, "decode: %d anchors per scale", d->num_anchors);
+    Y3_REQUIRE(d->batch >= 1 && d->batch <= 65535, Y3_E_INVALID, "decode: batch %d", d->batch);
+    DecodeArgs a;
+    a.d = *d;
+    const float *heads[3] = {head0, head1, head2};
+    int base = 0;
+    for (int l = 0; l < 3; ++l) {
+        a.scale_base[l] = base;
+        a.head[l] = heads[l < d->num_scales ? l : 0];
+        if (l < d->num_scales) {
+            Y3_REQUIRE(heads[l] != nullptr, Y3_E_INVALID, "decode: head %d is null", l);
+            Y3_REQUIRE(d->grid_h[l] > 0 && d->grid_w[l] > 0, Y3_E_INVALID, "decode: grid %d empty", l);
+            Y3_REQUIRE(d->head_ld[l] >= d->num_anchors * (5 + d->num_classes), Y3_E_INVALID, "decode: head_ld[%d]=%d too small", l, d->head_ld[l]);
+            base += d->grid_h[l] * d->grid_w[l] * d->num_anchors;
+        } else {
+            a.scale_base[l] = 0x7fffffff;
+            a.d.grid_h[l] = a.d.grid_w[l] = 1;
+        }
+    }
+    a.scale_base[3] = base;
+    Y3_REQUIRE(base == d->boxes_per_image, Y3_E_INVALID, "decode: boxes_per_image %d, grids give %d", d->boxes_per_image, base);
+    a.letterbox = letterbox; a.records = records; a.cand_idx = cand_idx; a.cand_count = cand_count; a.class_count = class_count;
+    dim3 grid((unsigned)((base + kChunk - 1) / kChunk), (unsigned)d->batch);
+    hipLaunchKernelGGL(decode_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+    return y3_check_launch("decode");
+}
+
+extern "C" int y3_get_head(const float *head, int batch, int grid_h, int grid_w, int head_ld, int num_anchors,
+                           int num_classes, const float *anchors_wh, float stride_x, float stride_y,
+                           float *box_xy, float *box_wh, float *conf, float *cls, void *stream) {
+    Y3_REQUIRE(head && anchors_wh && box_xy && box_wh && conf && cls, Y3_E_INVALID, "get_head: null pointer");
+    Y3_REQUIRE(batch > 0 && grid_h > 0 && grid_w > 0 && num_anchors > 0 && num_classes > 0, Y3_E_INVALID, "get_head: bad shape");
+    Y3_REQUIRE(head_ld >= num_anchors * (5 + num_classes), Y3_E_INVALID, "get_head: head_ld too small");
+    const long total = (long)batch * grid_h * grid_w * num_anchors * (5 + num_classes);
+    hipLaunchKernelGGL(get_head_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, head, total,
+                       grid_h, grid_w, head_ld, num_anchors, num_classes, anchors_wh, stride_x, stride_y,
+                       box_xy, box_wh, conf, cls);
+    return y3_check_launch("get_head");
+}
+
+extern "C" int y3_correct_boxes(const float *box_xy, const float *box_wh, int64_t n, float scale, float off_h,
+                                float off_w, float *boxes, void *stream) {
+    Y3_REQUIRE(box_xy && box_wh && boxes && n > 0, Y3_E_INVALID, "correct_boxes: bad arguments");
+    hipLaunchKernelGGL(correct_boxes_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, box_xy,
+                       box_wh, (long)n, scale, off_h, off_w, boxes);
+    return y3_check_launch("correct_boxes");
+}
+
+extern "C" int y3_expand_scores(const float *records, int64_t n, int num_classes, float *boxes, float *box_scores,
+                                void *stream) {
+    Y3_REQUIRE(records && boxes && box_scores && n > 0, Y3_E_INVALID, "expand_scores: bad arguments");
+    Y3_REQUIRE(num_classes >= 4 && num_classes <= kMaxClasses, Y3_E_INVALID, "expand_scores: %d classes", num_classes);
+    hipLaunchKernelGGL(expand_scores_kernel, dim3(grid_for(n * num_classes)), dim3(kThreads), 0, (hipStream_t)stream,
+                       records, (long)n, num_classes, boxes, box_scores);
+    return y3_check_launch("expand_scores");
+}

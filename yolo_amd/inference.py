@@ -1,0 +1,178 @@
+"""Image directory -> boxes / scores / classes: the MI355X counterpart of the reference's
+inference.py, same public names and argument order:
+
+    read_image(img_path)                    inference.py:28
+    get_classes(labels_path)                inference.py:56
+    read_anchors(file_path)                 inference.py:70
+    predict(output_nodes, anchors, num_classes, input_shape, image_shape)   inference.py:88
+    run_inference(img_path, output_dir, args)                               inference.py:170
+    CLI:  python -m yolo_amd.inference <img_dir> <out_dir> [--darknet_model 1]   inference.py:20-24
+
+predict() takes evaluated head tensors (what `sess.run(output_nodes)` would give) and runs
+the fused decode + per-class NMS kernels.  Drawing (inference.py:284-325) is reduced to the
+label-file contract; PIL is used for image decode in place of cv2 (absent here).
+"""
+import argparse
+import os
+from time import time
+
+import numpy as np
+import torch
+
+from . import config
+from .build_model import load_weights, yolo
+from .postprocess import PostProcessor
+from .utils.utils import resize_image
+
+parser = argparse.ArgumentParser(description="Run inference using darknet converted model")
+parser.add_argument("img_path", help="Path for running inference on a single image or multiple images")
+parser.add_argument("output_path", help="Output Path to save the results")
+parser.add_argument("--darknet_model", help="Weather to use pre-trained darknet yolov3")
+parser.add_argument("--weights", default=None, help="darknet .weights file (default: config.yolov3_weights_path)")
+parser.add_argument("--cfg", default=None, help="darknet .cfg file (default: config.yolov3_cfg_path)")
+parser.add_argument("--input_shape", type=int, default=None, help="network input size (default: config.input_shape)")
+parser.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
+
+
+def read_image(img_path):
+    """RGB uint8 arrays of every image in a directory, sorted by name (inference.py:28-52)."""
+    from PIL import Image
+    assert img_path is not None, "Image path required for making inference"
+    if not os.path.exists(img_path):
+        print("Path does not exists!!")
+        return None
+    names = sorted(os.listdir(img_path)) if os.path.isdir(img_path) else [None]
+    print("Reading {} images".format(len(names)))
+    images = []
+    for name in names:
+        path = img_path if name is None else os.path.join(img_path, name)
+        images.append(np.asarray(Image.open(path).convert("RGB")))
+    print("Read {} images".format(len(names)))
+    return images
+
+
+def get_classes(labels_path):
+    with open(labels_path) as f:
+        return [c.strip() for c in f.readlines()]
+
+
+def read_anchors(file_path):
+    """`w h` per line -> float array [n,2] (inference.py:70-84)."""
+    anchors = []
+    with open(file_path, "r") as fh:
+        for line in fh.read().splitlines():
+            if not line.strip():
+                continue
+            w, h = line.split()
+            anchors.append([float(w), float(h)])
+    return np.asarray(anchors)
+
+
+_POST = {}
+
+
+def _postprocessor(anchors, num_classes, input_shape, with_rank=False):
+    key = (np.asarray(anchors, dtype=np.float32).tobytes(), num_classes, tuple(input_shape), config.score_threshold,
+           config.nms_threshold, config.max_boxes, with_rank)
+    pp = _POST.get(key)
+    if pp is None:
+        pp = PostProcessor(anchors, num_classes, input_shape, config.score_threshold, config.nms_threshold,
+                           config.max_boxes, with_rank=with_rank)
+        _POST[key] = pp
+    return pp
+
+
+def predict_batch(output_nodes, anchors, num_classes, input_shape, image_shape):
+    """Batch form: B independent batch-1 reference runs (SURVEY 8a batch note).
+    image_shape: (h, w) or [B,2].  Returns postprocess.Detections (padded, on the GPU)."""
+    return _postprocessor(anchors, num_classes, input_shape)(list(output_nodes), image_shape)
+
+
+def predict(output_nodes, anchors, num_classes, input_shape, image_shape):
+    """Reference contract (inference.py:88-167): boxes [M,4] (y_min,x_min,y_max,x_max) fp32,
+    scores [M] fp32, classes [M] int32; class-major, within a class in NMS selection order.
+    Thresholds come from config (score_threshold, nms_threshold, max_boxes; inference.py:102-104).
+    Batch 1 returns the triple; batch B returns a list of B triples."""
+    det = predict_batch(output_nodes, anchors, num_classes, input_shape, image_shape)
+    counts = det.count.cpu().numpy()
+    out = [(det.boxes[b, :m].clone(), det.scores[b, :m].clone(), det.classes[b, :m].clone())
+           for b, m in enumerate(counts)]
+    return out[0] if len(out) == 1 else out
+
+
+def label_lines(out_boxes, out_scores, out_classes, image_hw):
+    """The labels/<stem>.txt lines (inference.py:291-308): rows in reverse order,
+    `left,top,right,bottom,class,score`, floor(v+0.5), clipped to the image."""
+    h, w = image_hw
+    lines = []
+    for i in reversed(range(len(out_classes))):
+        top, left, bottom, right = out_boxes[i]
+        top = max(0, np.floor(top + 0.5).astype(np.int32))
+        left = max(0, np.floor(left + 0.5).astype(np.int32))
+        bottom = min(h, np.floor(bottom + 0.5).astype(np.int32))
+        right = min(w, np.floor(right + 0.5).astype(np.int32))
+        lines.append(str(left) + "," + str(top) + "," + str(right) + "," + str(bottom) + "," + str(out_classes[i])
+                     + "," + str(out_scores[i]))
+    return lines
+
+
+def run_inference(img_path, output_dir, args):
+    """inference.py:170-331: every image of img_path -> output_dir/labels/<stem>.txt (+ a copy of
+    the image under output_dir/images), one image per step, FPS excluding the first image."""
+    for d in (output_dir, os.path.join(output_dir, "images"), os.path.join(output_dir, "labels")):
+        if not os.path.exists(d):
+            os.mkdir(d)
+    file_names = sorted(os.listdir(img_path))
+    images_batch = read_image(img_path)
+    class_names = get_classes(config.classes_path)
+    cfg_path = getattr(args, "cfg", None) or config.yolov3_cfg_path
+    tiny = "tiny" in os.path.basename(cfg_path)
+    anchors = read_anchors(config.tiny_anchors_path if tiny else config.anchors_path)
+    num_classes = config.num_classes
+    size = getattr(args, "input_shape", None) or config.input_shape
+    input_shape = (size, size)
+
+    output_nodes = yolo(input_images=None, is_training=False, config_path=cfg_path, num_classes=num_classes,
+                        dtype=getattr(args, "dtype", None))
+    weights = getattr(args, "weights", None) or config.yolov3_weights_path
+    if getattr(args, "darknet_model", None) is None and getattr(args, "weights", None) is None:
+        raise NotImplementedError("only Darknet .weights are supported (pass --darknet_model 1); the TF-checkpoint "
+                                  "branch of the reference (inference.py:258-266) is out of scope")
+    load_weights(output_nodes, weights)      # FileNotFoundError if absent: nothing is downloaded
+
+    total_time_pred = []
+    results = []
+    for x, image in enumerate(images_batch):
+        image_data = np.array(resize_image(image, input_shape))
+        print("Image height: {}\tImage width: {}".format(image.shape[0], image.shape[1]))
+        img = np.expand_dims(image_data / 255., 0).astype(np.float32)
+        tick = time()
+        heads = output_nodes(torch.from_numpy(img))
+        out_boxes, out_scores, out_classes = predict(heads, anchors, num_classes, input_shape,
+                                                     [image.shape[0], image.shape[1]])
+        out_boxes, out_scores, out_classes = (t.cpu().numpy() for t in (out_boxes, out_scores, out_classes))
+        tock = time()
+        total_time_pred.append(tock - tick)
+        print("Found {} boxes for {} in {}sec".format(len(out_boxes), "img", tock - tick))
+        lines = label_lines(out_boxes, out_scores, out_classes, image.shape[:2])
+        for i, c in reversed(list(enumerate(out_classes))):
+            print("{} {:.4f}".format(class_names[c], out_scores[i]))
+        with open(os.path.join(output_dir, "labels", file_names[x].split(".")[0] + ".txt"), "w") as fh:
+            fh.write("".join(l + "\n" for l in lines))
+        from PIL import Image
+        Image.fromarray(image.astype("uint8"), mode="RGB").save(os.path.join(output_dir, "images", file_names[x]))
+        results.append((out_boxes, out_scores, out_classes))
+    if len(images_batch) > 1:
+        t = sum(total_time_pred[1:])
+        print("FPS of model with post processing over {} images is {}".format(len(images_batch) - 1,
+                                                                             (len(images_batch) - 1) / t))
+    return results
+
+
+def main(args):
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(config.gpu_num))
+    run_inference(args.img_path, args.output_path, args)
+
+
+if __name__ == "__main__":
+    main(parser.parse_args())

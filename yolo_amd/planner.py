@@ -1,0 +1,374 @@
+"""Darknet cfg -> fused launch plan for the MI355X kernels.
+
+The reference walks the cfg and emits one TF op per section
+(build_model.py:97-255).  Here the same walk produces a *plan*: a short list of
+kernel launches over NHWC buffers in one arena, with
+  * BatchNorm folded into the conv weights, leaky-ReLU in the conv epilogue
+    (build_model.py:164-178),
+  * shortcut (build_model.py:218-227) fused into the producing conv as a residual
+    operand,
+  * upsample (build_model.py:231-239) fused into the producing conv as a 2x2
+    replicated store,
+  * route/concat (build_model.py:184-198) made zero-copy: producers write straight
+    into their channel slice of the concat buffer, single-input routes are aliases,
+and un-fused fallback kernels whenever a cfg does not fit those patterns.
+Pure Python, no torch / GPU: the plan is data, tests can interpret it on the CPU.
+"""
+import configparser
+import io
+import os
+from collections import defaultdict
+
+# head-conv indices chosen from the cfg file stem, build_model.py:64-73
+OUT_LAYERS = {"yolov3": [58, 66, 74], "yolov3-spp": [59, 67, 75], "yolov3-tiny": [9, 12, 12]}
+
+
+def unique_config_sections(cfg_file):
+    """Same contract as the reference's build_model.unique_config_sections
+    (build_model.py:12-32): returns a StringIO of the cfg in which every
+    `[section]` header carries a `_<count>` suffix, so configparser accepts it."""
+    counts = defaultdict(int)
+    stream = io.StringIO()
+    with open(cfg_file) as fh:
+        for line in fh:
+            if line.startswith("["):
+                name = line.strip().strip("[]")
+                line = line.replace(name, name + "_" + str(counts[name]))
+                counts[name] += 1
+            stream.write(line)
+    stream.seek(0)
+    return stream
+
+
+def parse_cfg(config_path, num_classes, num_anchors_per_scale=3, in_channels=3):
+    """cfg -> (layers, out_index).  One entry per non-[net] section, so list index ==
+    Darknet layer number; out_index = layers feeding each [yolo] (build_model.py:243-247)."""
+    config_path = os.path.expanduser(config_path)
+    assert config_path.endswith(".cfg"), "{} is not a .cfg file".format(config_path)   # build_model.py:51
+    if not os.path.exists(config_path):
+        raise FileNotFoundError("cfg file not found: %s" % config_path)
+    cfg = configparser.ConfigParser()
+    cfg.read_file(unique_config_sections(config_path))
+    stem = config_path.split("/")[-1].split(".")[0]
+    if stem not in OUT_LAYERS:
+        # the reference leaves out_layers undefined here and dies with NameError (build_model.py:68-73,132)
+        raise NameError("name 'out_layers' is not defined (cfg stem %r is not yolov3 / yolov3-spp / yolov3-tiny)" % stem)
+    heads = OUT_LAYERS[stem]
+
+    layers, chans, out_index = [], [], []
+    prev_c, conv_idx = in_channels, -1
+    for section in cfg.sections():
+        sec = cfg[section]
+        n = len(layers)
+        if section.startswith("convolutional"):
+            conv_idx += 1
+            is_head = conv_idx in heads
+            filters = num_anchors_per_scale * (num_classes + 5) if is_head else int(sec["filters"])
+            act = sec["activation"]
+            if act not in ("linear", "leaky"):
+                raise ValueError("Unsupported activation: %s" % act)
+            layers.append(dict(type="conv", conv_idx=conv_idx, cin=prev_c, filters=filters, size=int(sec["size"]),
+                               stride=int(sec["stride"]), pad=int(sec["pad"]), bn="batch_normalize" in sec,
+                               activation=act, head=is_head))
+            prev_c = filters
+        elif section.startswith("route"):
+            ids = [int(i) for i in sec["layers"].split(",")]
+            ids = [i if i >= 0 else n + i for i in ids]
+            layers.append(dict(type="route", ids=ids))
+            prev_c = sum(chans[i] for i in ids)
+        elif section.startswith("maxpool"):
+            layers.append(dict(type="maxpool", size=int(sec["size"]), stride=int(sec["stride"])))
+        elif section.startswith("shortcut"):
+            assert sec["activation"] == "linear", "Only linear activation is supported"
+            src = int(sec["from"])
+            layers.append(dict(type="shortcut", src=src if src >= 0 else n + src))
+        elif section.startswith("upsample"):
+            assert int(sec["stride"]) == 2, "Only stride=2 is supported"
+            layers.append(dict(type="upsample"))
+        elif section.startswith("yolo"):
+            out_index.append(n - 1)
+            layers.append(dict(type="yolo"))
+        elif section.startswith("net"):
+            continue
+        else:
+            raise ValueError("Unsupported section header type: {}".format(section))
+        chans.append(prev_c if layers[-1]["type"] != "yolo" else 0)
+    if not out_index:
+        out_index.append(len(layers) - 1)
+    return layers, out_index
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+def conv_out_hw(h, w, size, stride):
+    """Padding rule of build_model.py:124,151-154 (see y3_conv_desc)."""
+    pad = 1 if size == 3 else 0
+    if stride == 1:
+        return h, w
+    return (h + pad - size) // stride + 1, (w + pad - size) // stride + 1
+
+
+def infer_shapes(layers, in_h, in_w, in_c=3):
+    shapes = []
+    cur = (in_h, in_w, in_c)
+    for L in layers:
+        t = L["type"]
+        if t == "conv":
+            if L["size"] not in (1, 3) or L["stride"] not in (1, 2):
+                raise ValueError("conv size %d stride %d unsupported" % (L["size"], L["stride"]))
+            if L["size"] == 3 and L["pad"] != 1:
+                raise ValueError("3x3 conv with pad=0 unsupported")
+            h, w = conv_out_hw(cur[0], cur[1], L["size"], L["stride"])
+            cur = (h, w, L["filters"])
+        elif t == "maxpool":
+            s = L["stride"]
+            cur = (-(-cur[0] // s), -(-cur[1] // s), cur[2])
+        elif t == "upsample":
+            assert cur[0] == cur[1], "reference upsample is square-only (build_model.py:236)"
+            cur = (2 * cur[0], 2 * cur[1], cur[2])
+        elif t == "route":
+            srcs = [shapes[i] for i in L["ids"]]
+            assert all(s[:2] == srcs[0][:2] for s in srcs), "route: spatial sizes differ"
+            cur = (srcs[0][0], srcs[0][1], sum(s[2] for s in srcs))
+        elif t == "shortcut":
+            assert shapes[L["src"]] == cur, "shortcut: shapes differ"
+        elif t == "yolo":
+            shapes.append(None)
+            cur = None
+            continue
+        shapes.append(cur)
+    return shapes
+
+
+class Plan(object):
+    """ops: list of dicts; every tensor reference is (buf, elem_offset, ld) where buf is
+    'in' (network input), ('arena', byte_offset) or ('head', k)."""
+
+    def __init__(self):
+        self.ops = []
+        self.arena_bytes = 0
+        self.heads = []          # per head: dict(h, w, c, ld, layer)
+        self.shapes = None
+        self.batch = 0
+        self.dtype = "bf16"
+        self.conv_layers = []    # layer indices of convs, cfg order
+
+
+def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True):
+    assert dtype in ("bf16", "fp32")
+    es = 2 if dtype == "bf16" else 4
+    epc = 16 // es
+    shapes = infer_shapes(layers, in_h, in_w, in_c)
+    n = len(layers)
+
+    # ---- data-flow ------------------------------------------------------------------------
+    inputs = []
+    prev = -1
+    for i, L in enumerate(layers):
+        t = L["type"]
+        if t in ("conv", "maxpool", "upsample"):
+            inputs.append([prev])
+        elif t == "shortcut":
+            inputs.append([L["src"], prev])
+        elif t == "route":
+            inputs.append(list(L["ids"]))
+        else:
+            inputs.append([])
+        prev = None if t == "yolo" else i
+    for i, ins in enumerate(inputs):
+        if any(j is None for j in ins):
+            raise ValueError("layer %d consumes the output of a [yolo] section" % i)
+    uses = [0] * n
+    for ins in inputs:
+        for j in ins:
+            if j >= 0:
+                uses[j] += 1
+    head_of = {li: k for k, li in enumerate(out_index)}
+    for li in out_index:
+        if layers[li]["type"] != "conv":
+            raise ValueError("output layer %d is not a convolution" % li)
+
+    # ---- fusion decisions -------------------------------------------------------------------
+    fused_into = {}      # consumer layer (shortcut/upsample) -> producing conv
+    absorbed = {}        # conv -> consumer layer whose tensor it writes
+    if fuse:
+        for i, L in enumerate(layers):
+            if L["type"] not in ("shortcut", "upsample") or i == 0:
+                continue
+            p = inputs[i][-1]
+            if p < 0 or layers[p]["type"] != "conv" or uses[p] != 1 or p in head_of or p in absorbed:
+                continue
+            if layers[p]["cin"] % epc != 0:        # direct-conv family has no fused epilogue
+                continue
+            if L["type"] == "shortcut" and shapes[L["src"]] != shapes[p]:
+                continue
+            fused_into[i] = p
+            absorbed[p] = i
+
+    # ---- storage: aliases, concat slices, own buffers ---------------------------------------
+    bufs = []            # dict(elems, es, kind)
+    tens = [None] * n    # dict(buf, off, ld, c)  (off/ld in elements)
+
+    def new_buf(elems, esize=es, kind="arena"):
+        bufs.append(dict(elems=elems, es=esize, kind=kind))
+        return len(bufs) - 1
+
+    def pixels(i):
+        return batch * shapes[i][0] * shapes[i][1]
+
+    claimed = {}
+    concat_buf = {}
+    for i, L in enumerate(layers):
+        if L["type"] != "route" or len(L["ids"]) < 2:
+            continue
+        c_total = shapes[i][2]
+        ld = _ceil_to(c_total, epc)
+        b = new_buf(pixels(i) * ld)
+        concat_buf[i] = (b, ld)
+        off = 0
+        for j in L["ids"]:
+            cj = shapes[j][2]
+            ok = (j not in claimed and j not in head_of and j not in absorbed
+                  and layers[j]["type"] in ("conv", "maxpool", "upsample", "shortcut")
+                  and off % epc == 0 and cj % epc == 0 and L["ids"].count(j) == 1)
+            if ok:
+                claimed[j] = (b, off, ld)
+            off += cj
+
+    for i, L in enumerate(layers):
+        t = L["type"]
+        if t == "yolo" or i in absorbed:
+            continue
+        c = shapes[i][2]
+        if t == "route":
+            if len(L["ids"]) == 1:
+                src = tens[L["ids"][0]]
+                tens[i] = dict(src)
+            else:
+                b, ld = concat_buf[i]
+                tens[i] = dict(buf=b, off=0, ld=ld, c=c)
+            continue
+        if i in head_of:
+            ld = _ceil_to(c, 8)
+            b = new_buf(pixels(i) * ld, 4, kind=("head", head_of[i]))
+            tens[i] = dict(buf=b, off=0, ld=ld, c=c)
+        elif i in claimed:
+            b, off, ld = claimed[i]
+            tens[i] = dict(buf=b, off=off, ld=ld, c=c)
+        else:
+            ld = _ceil_to(c, epc)
+            tens[i] = dict(buf=new_buf(pixels(i) * ld), off=0, ld=ld, c=c)
+
+    in_tensor = dict(buf="in", off=0, ld=in_c, c=in_c)
+
+    def tin(j):
+        return in_tensor if j < 0 else tens[j]
+
+    # ---- emit ops ------------------------------------------------------------------------
+    plan = Plan()
+    plan.batch, plan.dtype, plan.shapes = batch, dtype, shapes
+    ops = plan.ops
+    for i, L in enumerate(layers):
+        t = L["type"]
+        if t == "conv":
+            plan.conv_layers.append(i)
+            src = inputs[i][0]
+            ih, iw, ic = (in_h, in_w, in_c) if src < 0 else shapes[src]
+            oh, ow, oc = shapes[i]
+            op = dict(kind="conv", layer=i, x=tin(src), in_hw=(ih, iw), in_c=ic, out_hw=(oh, ow), out_c=oc,
+                      ksize=L["size"], stride=L["stride"], leaky=L["activation"] == "leaky",
+                      in_f32=(src < 0), out_f32=(i in head_of), res=None, ups=False)
+            tgt = i
+            if i in absorbed:
+                tgt = absorbed[i]
+                if layers[tgt]["type"] == "shortcut":
+                    op["res"] = tens[layers[tgt]["src"]]
+                else:
+                    op["ups"] = True
+            op["y"] = tens[tgt]
+            op["writes_layer"] = tgt
+            ops.append(op)
+        elif t == "maxpool":
+            src = inputs[i][0]
+            ops.append(dict(kind="maxpool", layer=i, x=tin(src), y=tens[i], in_hw=shapes[src][:2], c=shapes[i][2],
+                            size=L["size"], stride=L["stride"]))
+        elif t == "upsample" and i not in fused_into:
+            src = inputs[i][0]
+            ops.append(dict(kind="upsample", layer=i, x=tin(src), y=tens[i], in_hw=shapes[src][:2], c=shapes[i][2]))
+        elif t == "shortcut" and i not in fused_into:
+            a, b2 = inputs[i]
+            ops.append(dict(kind="add", layer=i, a=tin(a), b=tin(b2), y=tens[i], pixels=pixels(i), c=shapes[i][2]))
+        elif t == "route" and len(L["ids"]) > 1:
+            b, ld = concat_buf[i]
+            off = 0
+            for j in L["ids"]:
+                cj = shapes[j][2]
+                if not (tens[j]["buf"] == b and tens[j]["off"] == off):
+                    if off % epc or cj % epc:
+                        raise ValueError("route %d: channel slice %d+%d is not 16-byte aligned" % (i, off, cj))
+                    ops.append(dict(kind="copy", layer=i, x=tens[j], y=dict(buf=b, off=off, ld=ld, c=cj),
+                                    pixels=pixels(i), c=cj))
+                off += cj
+
+    # ---- liveness + arena layout ------------------------------------------------------------
+    def refs(op, keys):
+        return [op[k]["buf"] for k in keys if op.get(k) is not None and op[k]["buf"] != "in"]
+
+    birth, death = {}, {}
+    for k, op in enumerate(ops):
+        for b in refs(op, ("y",)):
+            birth.setdefault(b, k)
+            death[b] = max(death.get(b, k), k)
+        for b in refs(op, ("x", "a", "b", "res")):
+            if b not in birth:
+                raise AssertionError("op %d reads buffer %d before it is written" % (k, b))
+            death[b] = max(death.get(b, k), k)
+    placed = []
+    offsets = {}
+    for b in sorted(birth, key=lambda q: (birth[q], -bufs[q]["elems"])):
+        if bufs[b]["kind"] != "arena":
+            continue
+        size = _ceil_to(bufs[b]["elems"] * bufs[b]["es"], 256)
+        taken = sorted((o, o + s) for (o, s, b0, d0) in placed if not (d0 < birth[b] or death[b] < b0))
+        pos = 0
+        for lo, hi in taken:
+            if pos + size <= lo:
+                break
+            pos = max(pos, hi)
+        placed.append((pos, size, birth[b], death[b]))
+        offsets[b] = pos
+        plan.arena_bytes = max(plan.arena_bytes, pos + size)
+
+    heads = [None] * len(out_index)
+    for b, info in enumerate(bufs):
+        if info["kind"] != "arena":
+            k = info["kind"][1]
+            li = out_index[k]
+            heads[k] = dict(h=shapes[li][0], w=shapes[li][1], c=shapes[li][2], ld=tens[li]["ld"], layer=li)
+    plan.heads = heads
+
+    def resolve(tn):
+        if tn is None or tn["buf"] == "in":
+            return tn
+        info = bufs[tn["buf"]]
+        where = ("arena", offsets[tn["buf"]]) if info["kind"] == "arena" else info["kind"]
+        return dict(buf=where, off=tn["off"], ld=tn["ld"], c=tn["c"])
+
+    for op in ops:
+        for k in ("x", "y", "a", "b", "res"):
+            if k in op:
+                op[k] = resolve(op[k])
+    return plan
+
+
+def conv_gflops(layers, in_h, in_w):
+    """2*MACs of all convolutions for one image (matches Darknet's printed BFLOPs)."""
+    shapes = infer_shapes(layers, in_h, in_w)
+    total = 0
+    for i, L in enumerate(layers):
+        if L["type"] == "conv":
+            h, w, c = shapes[i]
+            total += 2 * h * w * c * L["size"] ** 2 * L["cin"]
+    return total / 1e9
