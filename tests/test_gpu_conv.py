@@ -1,0 +1,132 @@
+"""-m gpu: the fused convolution kernels against the oracle's conv (numpy fp32), through the
+C-ABI.  fp32 mode: <= 1e-3 max-abs (north_star's head-tensor tolerance, applied per layer);
+bf16 mode: inputs/weights are rounded to bf16 first so that only accumulation order and the
+final bf16 rounding differ: |err| <= 1e-2 * max(1, |ref|)."""
+import numpy as np
+import pytest
+
+import gpu_util
+from oracle import darknet as od
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, kernel, bias, stride, leaky, residual=None, ups=False):
+    ks = kernel.shape[0]
+    xin = np.pad(x, ((0, 0), (1, 0), (1, 0), (0, 0))) if (stride > 1 and ks == 3) else x
+    y = od.conv2d(xin, kernel, stride, stride == 1) + bias
+    if leaky:
+        y = od.leaky_relu(y)
+    if residual is not None:
+        y = y + residual
+    if ups:
+        y = od.upsample2x_nearest(y)
+    return y.astype(np.float32)
+
+
+CASES = [
+    # B, H, Cin, Cout, ks, stride, leaky
+    (2, 13, 64, 128, 3, 1, True),       # BN=128 tile, M = 338 (not a tile multiple)
+    (1, 26, 128, 255, 1, 1, False),     # head: Cout 255 -> padded 256
+    (2, 16, 32, 64, 3, 2, True),        # stride 2, Cin=32 (bf16 k-step spans two taps), BN=64
+    (1, 20, 64, 32, 1, 1, True),        # BN=32
+    (1, 12, 16, 32, 3, 1, True),        # tiny layer 2: Cin=16
+    (1, 10, 384, 128, 1, 1, True),      # route input, Cin not a power of two
+    (3, 19, 96, 192, 3, 1, True),       # odd sizes: N tiles 2, K = 864 (padded to 896 in bf16)
+    (1, 7, 512, 1024, 3, 1, True),      # deep K (4608), 8 n-tiles
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_igemm(case, dtype):
+    B, H, C, O, ks, stride, leaky = case
+    rng = np.random.default_rng(abs(hash(case)) % 2 ** 31)
+    x = rng.standard_normal((B, H, H, C)).astype(np.float32)
+    k = (rng.standard_normal((ks, ks, C, O)) * np.sqrt(2.0 / (ks * ks * C))).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32)
+    if dtype == "bf16":
+        x, k = gpu_util.bf16_round(x), gpu_util.bf16_round(k)
+    got = gpu_util.run_conv(x, k, b, stride, dtype, leaky=leaky)
+    want = _ref(x, k, b, stride, leaky)
+    assert got.shape == want.shape
+    if dtype == "fp32":
+        assert np.abs(got - want).max() <= 1e-3
+    else:
+        assert np.all(np.abs(got - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_residual_and_slices(dtype):
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((2, 14, 14, 64)).astype(np.float32)
+    k = (rng.standard_normal((3, 3, 64, 128)) * 0.06).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    r = rng.standard_normal((2, 14, 14, 128)).astype(np.float32)
+    if dtype == "bf16":
+        x, k, r = gpu_util.bf16_round(x), gpu_util.bf16_round(k), gpu_util.bf16_round(r)
+    got = gpu_util.run_conv(x, k, b, 1, dtype, leaky=True, residual=r, in_pad=(16, 8), out_pad=(8, 24))
+    want = _ref(x, k, b, 1, True, residual=r)
+    tol = 1e-3 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(want))
+    assert np.all(np.abs(got - want) <= tol)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_upsample_store(dtype):
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal((2, 13, 13, 256)).astype(np.float32)
+    k = (rng.standard_normal((1, 1, 256, 128)) * 0.09).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    if dtype == "bf16":
+        x, k = gpu_util.bf16_round(x), gpu_util.bf16_round(k)
+    got = gpu_util.run_conv(x, k, b, 1, dtype, leaky=True, ups=True, out_pad=(0, 256))
+    want = _ref(x, k, b, 1, True, ups=True)
+    assert got.shape == (2, 26, 26, 128)
+    tol = 1e-3 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(want))
+    assert np.all(np.abs(got - want) <= tol)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_head_fp32_output(dtype):
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((1, 19, 19, 256)).astype(np.float32)
+    k = (rng.standard_normal((1, 1, 256, 255)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(255).astype(np.float32)
+    if dtype == "bf16":
+        x, k = gpu_util.bf16_round(x), gpu_util.bf16_round(k)
+    got = gpu_util.run_conv(x, k, b, 1, dtype, leaky=False, out_f32=True)
+    want = _ref(x, k, b, 1, False)
+    assert np.abs(got - want).max() <= 1e-3          # fp32 store: no output rounding in either mode
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("cout", [16, 32])
+def test_conv_first_layer_direct(dtype, cout):
+    rng = np.random.default_rng(24 + cout)
+    x = rng.random((2, 33, 33, 3), dtype=np.float32)
+    k = (rng.standard_normal((3, 3, 3, cout)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    got = gpu_util.run_conv(x, k, b, 1, dtype, leaky=True, in_f32=True)
+    want = _ref(x, k, b, 1, True)
+    tol = 1e-4 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(want))
+    assert np.all(np.abs(got - want) <= tol)
+
+
+def test_conv_rejects_bad_arguments():
+    import ctypes
+    import torch
+    from yolo_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = 1, 1, 8, 8, 32, 32
+    d.out_h, d.out_w, d.out_c, d.out_ld, d.ksize, d.stride, d.k_pad, d.n_pad = 8, 8, 64, 64, 3, 1, 320, 64
+    t = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    p = t.data_ptr()
+    assert lib.y3_conv2d_fused(ctypes.byref(d), p, p, p, None, p, p, None) == 0
+    d.out_h = 9
+    assert lib.y3_conv2d_fused(ctypes.byref(d), p, p, p, None, p, p, None) == -1
+    d.out_h = 8
+    assert lib.y3_conv2d_fused(ctypes.byref(d), p + 2, p, p, None, p, p, None) == -2      # misaligned input
+    d.k_pad = 288
+    assert lib.y3_conv2d_fused(ctypes.byref(d), p, p, p, None, p, p, None) == -1
+    torch.cuda.synchronize()

@@ -1,0 +1,105 @@
+"""-m gpu: fused decode kernel and the dense helper kernels against the oracle's decode.
+Floating point: boxes within 1e-5 relative (+1e-4 px absolute), scores within 2e-6 absolute --
+the only differences are the last ulps of expf / division between the GPU and numpy.  Class
+masks must be identical wherever the top-2 class probabilities are not within 1e-6."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode as odec
+from yolo_amd import inference
+from yolo_amd.postprocess import PostProcessor
+from yolo_amd.utils import utils as yu
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+COCO = np.array([(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119), (116, 90), (156, 198), (373, 326)], dtype=np.float32)
+TINY = np.array([(10, 14), (23, 27), (37, 58), (81, 82), (135, 169), (344, 319)], dtype=np.float32)
+
+
+def _heads(rng, B, grids, scale=1.5):
+    return [(rng.standard_normal((B, g, g, 255)) * scale).astype(np.float32) for g in grids]
+
+
+def _mask_to_dense(rec, C=80):
+    m = rec[..., 5:8].copy().view(np.uint32)
+    out = np.zeros(rec.shape[:-1] + (C,), dtype=bool)
+    for c in range(C):
+        out[..., c] = ((m[..., c >> 5] >> np.uint32(c & 31)) & 1) != 0
+    return out
+
+
+@pytest.mark.parametrize("grids,anchors,size,image_shape", [
+    ((13, 26, 52), COCO, 416, (416, 416)),
+    ((19, 38, 76), COCO, 608, (375, 500)),
+    ((13, 26), TINY, 416, (720, 1280)),
+])
+def test_fused_decode_matches_oracle(grids, anchors, size, image_shape):
+    rng = np.random.default_rng(size + len(grids))
+    B = 3
+    heads = _heads(rng, B, grids)
+    pp = PostProcessor(anchors, 80, (size, size), score_threshold=0.3)
+    det = pp([torch.from_numpy(h).cuda() for h in heads], image_shape)
+    torch.cuda.synchronize()
+    rec = det.records.cpu().numpy()
+    cand_count = det.cand_count.cpu().numpy()
+    for b in range(B):
+        boxes, scores = odec.pooled_boxes_and_scores([h[b:b + 1] for h in heads], anchors, 80, (size, size), image_shape)
+        np.testing.assert_allclose(rec[b, :, :4], boxes, rtol=1e-5, atol=1e-4)
+        best = scores.max(axis=1)
+        np.testing.assert_allclose(rec[b, :, 4], best, rtol=0, atol=2e-6)
+        top2 = np.sort(np.concatenate([h[b].reshape(-1, 85)[:, 5:] for h in heads]), axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+        np.testing.assert_array_equal(_mask_to_dense(rec[b])[clear], (scores > 0)[clear])
+        n_or = int((best >= np.float32(0.3)).sum())
+        assert abs(int(cand_count[b]) - n_or) <= 2          # borderline scores may flip by an ulp
+
+
+def test_decode_known_answers_on_gpu():
+    gold = json.load(open(os.path.join(GOLD, "decode_cases.json")))
+    for case in gold["cases"]:
+        g = case["grid"]
+        out = torch.zeros((1, g, g, 255), dtype=torch.float32, device="cuda")
+        anchors = np.array([case["anchor_wh"]] * 3, dtype=np.float32)
+        boxes, scores = yu.get_boxes_and_scores(out, anchors, 80, tuple(case["input_shape"]), tuple(case["image_shape"]))
+        gx, gy = case["cell_xy"]
+        p = (gy * g + gx) * 3
+        np.testing.assert_array_equal(boxes[p].cpu().numpy(), np.float32(case["box_yxyx"]))
+        assert torch.all(scores[p] == case["score_every_class"])         # 80-way tie: every class keeps the score
+        xy, wh, conf, cls = yu.get_head(out, anchors, 80, tuple(case["input_shape"]))
+        np.testing.assert_array_equal(xy[0, gy, gx, 0].cpu().numpy(), np.float32(case["box_xy"]))
+        np.testing.assert_array_equal(wh[0, gy, gx, 0].cpu().numpy(), np.float32(case["box_wh"]))
+        assert float(conf[0, gy, gx, 0, 0]) == case["conf"] and torch.all(cls == case["cls"])
+
+
+def test_dense_helpers_match_oracle():
+    rng = np.random.default_rng(77)
+    out = (rng.standard_normal((2, 13, 13, 255)) * 1.5).astype(np.float32)
+    anchors = COCO[[6, 7, 8]]
+    t = torch.from_numpy(out).cuda()
+    xy, wh, conf, cls = yu.get_head(t, anchors, 80, (416, 416))
+    oxy, owh, oconf, ocls = odec.get_head(out, anchors, 80, (416, 416))
+    assert tuple(xy.shape) == oxy.shape and tuple(cls.shape) == ocls.shape and tuple(conf.shape) == oconf.shape
+    np.testing.assert_allclose(xy.cpu().numpy(), oxy, rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(wh.cpu().numpy(), owh, rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(conf.cpu().numpy(), oconf, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(cls.cpu().numpy(), ocls, rtol=0, atol=2e-7)
+    boxes = yu.correct_boxes(torch.from_numpy(oxy).cuda(), torch.from_numpy(owh).cuda(), (416, 416), (300, 500))
+    np.testing.assert_allclose(boxes.cpu().numpy(), odec.correct_boxes(oxy, owh, (416, 416), (300, 500)), rtol=1e-6, atol=1e-4)
+    b, s = yu.get_boxes_and_scores(t, anchors, 80, (416, 416), (300, 500))
+    ob, os_ = odec.get_boxes_and_scores(out, anchors, 80, (416, 416), (300, 500))
+    assert tuple(b.shape) == ob.shape and tuple(s.shape) == os_.shape
+    np.testing.assert_allclose(b.cpu().numpy(), ob, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(s.cpu().numpy(), os_, rtol=0, atol=2e-6)
+
+
+def test_head_with_plain_contiguous_layout_and_bad_channels():
+    out = torch.zeros((1, 13, 13, 255), device="cuda")
+    pp = PostProcessor(COCO, 80, (416, 416))
+    with pytest.raises(ValueError):
+        pp([out[..., :250]], (416, 416))
+    with pytest.raises(ValueError):
+        inference.predict([out, out], TINY, 20, (416, 416), (416, 416))

@@ -1,0 +1,177 @@
+"""-m gpu: whole hot path, cfg -> heads -> decode -> NMS, against the oracle.
+
+Tolerances (BASELINE.json north_star): head tensors <= 1e-3 max-abs in fp32 mode and
+<= 2e-2 relative (max-abs error / max-abs reference, per head tensor) in bf16 mode; NMS
+bit-exact given the HIP-decoded boxes.  PARITY UNPINNED w.r.t. TensorFlow itself (see
+oracle/__init__.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import darknet as od
+from oracle import decode as odec
+from yolo_amd import build_model, config, inference
+from yolo_amd import darknet_weights as dw
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(cfg, dtype, seed, tmp_path=None):
+    layers, out_index = od.parse_layers(cfg, 80)
+    params = dw.random_params(layers, seed=seed)
+    nodes = build_model.yolo(None, False, cfg, 80, dtype=dtype)
+    if tmp_path is not None:           # through the Darknet file format, like the reference
+        path = os.path.join(str(tmp_path), "w.weights")
+        dw.write_weights(path, nodes.net.layers, params)
+        build_model.load_weights(nodes, path)
+    else:
+        nodes.net.set_params(params)
+    return nodes, layers, out_index, params
+
+
+def _dense_from_records(rec, C=80):
+    m = rec[:, 5:8].copy().view(np.uint32)
+    scores = np.zeros((rec.shape[0], C), dtype=np.float32)
+    for c in range(C):
+        scores[:, c] = np.where((m[:, c >> 5] >> np.uint32(c & 31)) & 1, rec[:, 4], 0)
+    return rec[:, :4], scores
+
+
+def _check_nms_exact(det, b, thr):
+    boxes, scores = _dense_from_records(det.records[b].cpu().numpy())
+    ob, os_, oc = odec.select(boxes, scores, thr, config.nms_threshold, config.max_boxes)
+    m = int(det.count[b].item())
+    assert m == len(oc)
+    np.testing.assert_array_equal(det.classes[b, :m].cpu().numpy(), oc)
+    np.testing.assert_array_equal(det.boxes[b, :m].cpu().numpy(), ob)
+    np.testing.assert_array_equal(det.scores[b, :m].cpu().numpy(), os_)
+    return m
+
+
+def test_config2_tiny416_b32_fp32(tmp_path):
+    """BASELINE config 2: YOLOv3-tiny 416 batch 32 fp32: conv + decode + NMS parity."""
+    nodes, layers, oi, params = _net(config.yolov3_tiny_cfg_path, "fp32", 1, tmp_path)
+    x = np.random.default_rng(1).random((32, 416, 416, 3), dtype=np.float32)
+    heads = nodes(torch.from_numpy(x))
+    torch.cuda.synchronize()
+    ref = od.forward(layers, oi, params, x)
+    for h, r in zip(heads, ref):
+        assert tuple(h.shape) == r.shape
+        assert np.abs(h.cpu().numpy() - r).max() <= 1e-3
+    anchors = inference.read_anchors(config.tiny_anchors_path)
+    det = inference.predict_batch(heads, anchors, 80, (416, 416), (416, 416))
+    total = sum(_check_nms_exact(det, b, config.score_threshold) for b in range(32))
+    assert total > 0
+    # decode of the HIP heads vs decode of the oracle heads (fp32 tolerance)
+    boxes, scores = odec.pooled_boxes_and_scores([r[:1] for r in ref], anchors, 80, (416, 416), (416, 416))
+    rec0 = det.records[0].cpu().numpy()
+    np.testing.assert_allclose(rec0[:, :4], boxes, rtol=1e-3, atol=0.5)
+    np.testing.assert_allclose(rec0[:, 4], scores.max(axis=1), rtol=0, atol=2e-3)
+
+
+def test_reference_style_predict_batch1():
+    nodes, layers, oi, params = _net(config.yolov3_tiny_cfg_path, "fp32", 2)
+    x = np.random.default_rng(2).random((1, 416, 416, 3), dtype=np.float32)
+    heads = nodes(torch.from_numpy(x))
+    anchors = inference.read_anchors(config.tiny_anchors_path)
+    boxes, scores, classes = inference.predict(heads, anchors, 80, (416, 416), [375, 500])
+    assert boxes.dtype == torch.float32 and classes.dtype == torch.int32 and boxes.shape[1] == 4
+    assert boxes.shape[0] == scores.shape[0] == classes.shape[0] > 0
+    assert torch.all(classes[1:] >= classes[:-1])
+    lines = inference.label_lines(boxes.cpu().numpy(), scores.cpu().numpy(), classes.cpu().numpy(), (375, 500))
+    want = odec.label_lines(boxes.cpu().numpy(), scores.cpu().numpy(), classes.cpu().numpy(), (375, 500))
+    assert lines == want
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_yolov3_416_heads(dtype):
+    """Darknet-53 416 (config 3 at batch 2 so the oracle finishes in seconds)."""
+    nodes, layers, oi, params = _net(config.yolov3_cfg_path, dtype, 3)
+    x = np.random.default_rng(3).random((2, 416, 416, 3), dtype=np.float32)
+    heads = nodes(torch.from_numpy(x))
+    torch.cuda.synchronize()
+    ref = od.forward(layers, oi, params, x)
+    for h, r in zip(heads, ref):
+        err = np.abs(h.cpu().numpy() - r).max()
+        if dtype == "fp32":
+            assert err <= 1e-3
+        else:
+            assert err / np.abs(r).max() <= 2e-2
+    anchors = inference.read_anchors(config.anchors_path)
+    det = inference.predict_batch(heads, anchors, 80, (416, 416), (416, 416))
+    for b in range(2):
+        assert _check_nms_exact(det, b, config.score_threshold) > 0
+
+
+def test_unfused_plan_equals_fused_plan():
+    """Fallback kernels (upsample / add) give the same heads as the fused epilogues."""
+    layers, oi = od.parse_layers(config.yolov3_cfg_path, 80)
+    params = dw.random_params(layers, seed=4)
+    x = torch.from_numpy(np.random.default_rng(4).random((1, 224, 224, 3), dtype=np.float32))
+    outs = []
+    for fuse in (True, False):
+        net = build_model.Network(config.yolov3_cfg_path, 80, dtype="fp32", fuse=fuse)
+        net.set_params(params)
+        outs.append([h.cpu().numpy() for h in net(x)])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)          # same arithmetic, same order: bit-identical
+
+
+def test_full_size_properties_608_bf16():
+    """BASELINE full size (608, bf16, batch 16 here): size-independent properties --
+    an image's result does not depend on its batch position or on chunking, and the
+    per-image NMS output equals the oracle's NMS of the same decoded boxes."""
+    nodes, layers, oi, params = _net(config.yolov3_cfg_path, "bf16", 5)
+    rng = np.random.default_rng(5)
+    x = rng.random((16, 608, 608, 3), dtype=np.float32)
+    x[9] = x[0]
+    xt = torch.from_numpy(x).cuda()
+    heads = [h.clone() for h in nodes(xt)]
+    heads_chunked = [h.clone() for h in nodes(xt, chunk=5)]
+    for a, b in zip(heads, heads_chunked):
+        assert torch.equal(a, b)
+        assert torch.equal(a[0], a[9])
+    assert [tuple(h.shape) for h in heads] == [(16, 19, 19, 255), (16, 38, 38, 255), (16, 76, 76, 255)]
+    anchors = inference.read_anchors(config.anchors_path)
+    det = inference.predict_batch(heads, anchors, 80, (608, 608), (608, 608))
+    m0 = _check_nms_exact(det, 0, config.score_threshold)
+    m9 = _check_nms_exact(det, 9, config.score_threshold)
+    assert m0 == m9 > 0 and torch.equal(det.boxes[0, :m0], det.boxes[9, :m9])
+
+
+def test_dense_stress_config5():
+    """BASELINE config 5: 608, low score threshold -> ~10k+ candidates per image into NMS."""
+    rng = np.random.default_rng(7)
+    B = 2
+    heads = []
+    for g in (19, 38, 76):
+        t = np.empty((B, g, g, 3, 85), dtype=np.float32)
+        t[..., 0:2] = rng.standard_normal((B, g, g, 3, 2))
+        t[..., 2:4] = rng.standard_normal((B, g, g, 3, 2)) * 0.5
+        t[..., 4] = rng.standard_normal((B, g, g, 3)) * 2
+        t[..., 5:] = rng.standard_normal((B, g, g, 3, 80)) * 2 - 2
+        heads.append(torch.from_numpy(t.reshape(B, g, g, 255)).cuda())
+    anchors = inference.read_anchors(config.anchors_path)
+    old = config.score_threshold
+    config.score_threshold = 0.001
+    try:
+        det = inference.predict_batch(heads, anchors, 80, (608, 608), (608, 608))
+        counts = det.cand_count.cpu().numpy()
+        assert np.all(counts > 8000)
+        for b in range(B):
+            m = _check_nms_exact(det, b, 0.001)
+            assert m > 1000
+    finally:
+        config.score_threshold = old
+
+
+def test_missing_weights_raise_and_nothing_is_fetched(tmp_path):
+    nodes = build_model.yolo(None, False, config.yolov3_tiny_cfg_path, 80)
+    with pytest.raises(FileNotFoundError):
+        build_model.load_weights(nodes, str(tmp_path / "yolov3.weights"))
+    with pytest.raises(RuntimeError):
+        nodes(torch.zeros((1, 416, 416, 3)))
+    with pytest.raises(ValueError):
+        build_model.yolo(None, True, config.yolov3_tiny_cfg_path, 80)

@@ -35,6 +35,26 @@ def _dtype_code(dtype):
     return _lib.Y3_BF16 if dtype == "bf16" else _lib.Y3_F32
 
 
+def pack_conv(kernel, bias, dtype, in_f32, device):
+    """Folded HWIO kernel + bias -> (weights, bias, family, k_pad, n_pad) in the layout
+    y3_conv_weight_layout prescribes (include/yolo3hip.h)."""
+    kh, kw, ci, co = kernel.shape
+    fam, k_pad, n_pad = _lib.conv_weight_layout(_dtype_code(dtype), ci, co, kh, in_f32=in_f32)
+    bias_p = np.zeros(n_pad, dtype=np.float32)
+    bias_p[:co] = bias
+    if fam == 0:      # implicit GEMM: [n_pad][k_pad], k = (kh*ks + kw)*Cin + c
+        wp = np.zeros((n_pad, k_pad), dtype=np.float32)
+        wp[:co, :kh * kw * ci] = np.transpose(kernel, (3, 0, 1, 2)).reshape(co, -1)
+        wt = torch.from_numpy(wp)
+        if dtype == "bf16":
+            wt = wt.to(torch.bfloat16)
+    else:             # direct: fp32 [k][n_pad]
+        wp = np.zeros((kh * kw * ci, n_pad), dtype=np.float32)
+        wp[:, :co] = kernel.reshape(-1, co)
+        wt = torch.from_numpy(wp)
+    return wt.to(device).contiguous(), torch.from_numpy(bias_p).to(device), fam, k_pad, n_pad
+
+
 class _CompiledPlan(object):
     """A planner.Plan bound to device memory: an arena, and one prepared launcher per op."""
 
@@ -140,7 +160,6 @@ class Network(object):
     # ---- weights ---------------------------------------------------------------------------
     def set_params(self, params):
         """params: {layer: {'kernel' HWIO, 'gamma','beta','mean','var' | 'bias'}} (fp32 numpy)."""
-        code = _dtype_code(self.dtype)
         packed = {}
         first_conv = next(i for i, L in enumerate(self.layers) if L["type"] == "conv")
         for li, L in enumerate(self.layers):
@@ -149,20 +168,7 @@ class Network(object):
             kernel, bias = dw.fold_batch_norm(params[li])
             kh, kw, ci, co = kernel.shape
             assert (kh, ci, co) == (L["size"], L["cin"], L["filters"]), "layer %d: kernel shape %r" % (li, kernel.shape)
-            fam, k_pad, n_pad = _lib.conv_weight_layout(code, ci, co, kh, in_f32=(li == first_conv))
-            bias_p = np.zeros(n_pad, dtype=np.float32)
-            bias_p[:co] = bias
-            if fam == 0:      # implicit GEMM: [n_pad][k_pad], k = (kh*ks + kw)*Cin + c
-                wp = np.zeros((n_pad, k_pad), dtype=np.float32)
-                wp[:co, :kh * kw * ci] = np.transpose(kernel, (3, 0, 1, 2)).reshape(co, -1)
-                wt = torch.from_numpy(wp)
-                if self.dtype == "bf16":
-                    wt = wt.to(torch.bfloat16)
-            else:             # direct: fp32 [k][n_pad]
-                wp = np.zeros((kh * kw * ci, n_pad), dtype=np.float32)
-                wp[:, :co] = kernel.reshape(-1, co)
-                wt = torch.from_numpy(wp)
-            packed[li] = (wt.to(self.device).contiguous(), torch.from_numpy(bias_p).to(self.device), fam, k_pad, n_pad)
+            packed[li] = pack_conv(kernel, bias, self.dtype, li == first_conv, self.device)
         self.params = params
         self._packed = packed
         self._zeros = torch.zeros(256, dtype=torch.uint8, device=self.device)
