@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Headline benchmark: YOLOv3-608 end-to-end (backbone + decode + per-class NMS) images/sec.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: 64 images of 608x608x3 per GPU (BASELINE.json configs[3]), seeded
+random-init Darknet-53 weights, bf16 compute.  Ranks shard the global batch by image
+(no data-path collective); rank 0 prints ONE JSON line.  `roofline` prices the dominant
+kernel (the 128x128-tile bf16 implicit-GEMM convolution) against the dense bf16 MFMA peak
+from HIP-event timings taken inside the timed region; `cpu_baseline` times the numpy/C
+oracle (a CPU restatement, NOT TensorFlow) on the host cores for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from yolo_amd import build_model, config, inference, planner, sharding  # noqa: E402
+from yolo_amd import darknet_weights as dw  # noqa: E402
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md chip table
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="yolov3", choices=["yolov3", "yolov3-tiny"])
+    ap.add_argument("--size", type=int, default=608)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--chunk", type=int, default=0, help="sub-batch the plan runs at a time (0 = whole batch)")
+    ap.add_argument("--score-threshold", type=float, default=config.score_threshold)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=4, help="timed images of the CPU baseline (plus 1 warm-up)")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+def conv_flops(op, batch):
+    oh, ow = op["out_hw"]
+    return 2.0 * batch * oh * ow * op["out_c"] * op["ksize"] ** 2 * op["in_c"]
+
+
+def is_dominant(op, dtype):
+    """The launches that run conv_igemm_kernel<bf16, 128, 128, 2, 2> (Cout > 64, chunked Cin)."""
+    epc = 8 if dtype == "bf16" else 4
+    return op["kind"] == "conv" and op["out_c"] > 64 and op["in_c"] % epc == 0 and not op["in_f32"]
+
+
+def cpu_baseline(model_cfg, size, n_images, score_threshold):
+    """Oracle (oracle/: numpy + C restatement of the reference path) on the host cores, batch 1,
+    FPS as inference.py:329-331 defines it (first image excluded)."""
+    from oracle import darknet as od, decode as odec
+    layers, out_index = od.parse_layers(model_cfg, config.num_classes)
+    params = dw.random_params(layers, seed=0)
+    anchors = inference.read_anchors(config.tiny_anchors_path if "tiny" in model_cfg else config.anchors_path)
+    rng = np.random.default_rng(1234)
+    times = []
+    for i in range(n_images + 1):
+        x = rng.random((1, size, size, 3), dtype=np.float32)
+        t0 = time.time()
+        heads = od.forward(layers, out_index, params, x)
+        odec.predict(heads, anchors, config.num_classes, (size, size), (size, size), score_threshold,
+                     config.nms_threshold, config.max_boxes)
+        times.append(time.time() - t0)
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    return {"value": round(n_images / sum(times[1:]), 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": "%d images of %dx%d, batch 1, after 1 warm-up image; numpy(BLAS)+C oracle, not TensorFlow"
+                      % (n_images, size, size)}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = config.yolov3_tiny_cfg_path if args.model == "yolov3-tiny" else config.yolov3_cfg_path
+    anchors = inference.read_anchors(config.tiny_anchors_path if args.model == "yolov3-tiny" else config.anchors_path)
+    config.score_threshold = args.score_threshold
+    B, S = args.batch, args.size
+
+    nodes = build_model.yolo(None, False, cfg, config.num_classes, dtype=args.dtype, device=dev)
+    net = nodes.net
+    net.set_params(dw.random_params(net.layers, seed=0))          # every rank: same seeded weights
+    lo, hi = sharding.shard_range(world * B, rank, world)         # this rank's images of the global batch
+    gen = torch.Generator(device="cpu").manual_seed(100 + rank)
+    images = torch.rand((hi - lo, S, S, 3), generator=gen, dtype=torch.float32).to(dev)
+    chunk = args.chunk or None
+
+    def step(trace=None):
+        heads = net.forward(images, chunk=chunk, trace=trace)
+        return inference.predict_batch(heads, anchors, config.num_classes, (S, S), (S, S))
+
+    for _ in range(args.warmup):
+        det = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    traces = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr = None if args.no_kernel_events else []
+        det = step(tr)
+        if tr is not None:
+            traces.append(tr)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    counts = sharding.gather_counts(det.count)                    # the one collective, off the timed path
+    total_images = world * B * args.steps
+    value = total_images / elapsed
+
+    if rank == 0:
+        plan = net.plan_for(chunk or (hi - lo), S, S).plan
+        gflop_img = planner.conv_gflops(net.layers, S, S)
+        out = {
+            "metric": "images/sec (whole node) YOLOv3-608 end-to-end incl. NMS; conv MFMA util %",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s %dx%d, batch %d per GPU, %s, seeded random-init Darknet weights, backbone + "
+                                   "decode + per-class NMS (score>=%.3g, iou>0.3, max 51/class)"
+                                   % (args.model, S, S, B, args.dtype, args.score_threshold),
+                       "global_batch": world * B, "parallelism": "dp%d (image-sharded, no data-path collective)" % world,
+                       "chunk": chunk or B, "conv_gflop_per_image": round(gflop_img, 3),
+                       "mean_detections_per_image": round(float(counts.float().mean().item()), 2)},
+            "conv_mfma_util_pct_end_to_end": round(100.0 * gflop_img * value / world / 1e3 /
+                                                   (BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS), 2),
+        }
+        if traces:
+            nb = chunk or (hi - lo)
+            dom_ms, dom_flops, dom_n, conv_ms, other_ms = 0.0, 0.0, 0, 0.0, 0.0
+            for tr in traces:
+                for op, e0, e1 in tr:
+                    ms = e0.elapsed_time(e1)
+                    if is_dominant(op, args.dtype):
+                        dom_ms += ms; dom_flops += conv_flops(op, nb); dom_n += 1
+                    if op["kind"] == "conv":
+                        conv_ms += ms
+                    else:
+                        other_ms += ms
+            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+            achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(achieved / peak, 4), "traffic": None,
+                               "kernel": "conv_igemm_kernel<%s,128,128,2,2>" % args.dtype,
+                               "launches_per_step": dom_n // len(traces),
+                               "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
+                               "avg_gflop_per_launch": round(dom_flops / max(dom_n, 1) / 1e9, 3)}
+            out["stage_ms_per_step"] = {"conv_all": round(conv_ms / len(traces), 3),
+                                        "other_layers": round(other_ms / len(traces), 3),
+                                        "decode_nms_pack_and_gaps": round(1e3 * elapsed / args.steps - (conv_ms + other_ms) / len(traces), 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, S, args.cpu_images, args.score_threshold)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

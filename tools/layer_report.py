@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Per-launch timing report of one forward plan (HIP events), with each launch priced against
+its own roofline: MFMA time at the dense peak and HBM time for its algorithmic bytes."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yolo_amd import build_model, config  # noqa: E402
+from yolo_amd import darknet_weights as dw  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="yolov3")
+    ap.add_argument("--size", type=int, default=608)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    cfg = config.yolov3_tiny_cfg_path if a.model == "yolov3-tiny" else config.yolov3_cfg_path
+    net = build_model.Network(cfg, 80, dtype=a.dtype)
+    net.set_params(dw.random_params(net.layers, seed=0))
+    x = torch.rand((a.batch, a.size, a.size, 3), device="cuda")
+    for _ in range(2):
+        net.forward(x, chunk=a.chunk or None)
+    torch.cuda.synchronize()
+    acc = {}
+    for _ in range(a.reps):
+        tr = []
+        net.forward(x, chunk=a.chunk or None, trace=tr)
+        torch.cuda.synchronize()
+        for i, (op, e0, e1) in enumerate(tr):
+            acc.setdefault(i, [op, []])[1].append(e0.elapsed_time(e1))
+    es = 2 if a.dtype == "bf16" else 4
+    peak = 2500e12 if a.dtype == "bf16" else 157.3e12
+    nb = a.chunk or a.batch
+    tot = tot_ideal = 0.0
+    print("%3s %5s %-22s %9s %8s %8s %8s %7s" % ("op", "layer", "shape", "ms", "TFLOP/s", "GB/s", "ideal_ms", "eff"))
+    for i in sorted(acc):
+        op, ts = acc[i]
+        ms = float(np.median(ts))
+        if op["kind"] == "conv":
+            oh, ow = op["out_hw"]; ih, iw = op["in_hw"]
+            flops = 2.0 * nb * oh * ow * op["out_c"] * op["ksize"] ** 2 * op["in_c"]
+            ies = 4 if op["in_f32"] else es
+            oes = 4 if op["out_f32"] else es
+            byt = nb * ih * iw * op["in_c"] * ies + nb * oh * ow * op["out_c"] * oes * (4 if op["ups"] else 1)
+            byt += op["out_c"] * op["ksize"] ** 2 * op["in_c"] * es
+            if op["res"] is not None:
+                byt += nb * oh * ow * op["out_c"] * es
+            shape = "%dx%d s%d %d->%d @%d%s%s" % (op["ksize"], op["ksize"], op["stride"], op["in_c"], op["out_c"], oh,
+                                                  "+r" if op["res"] is not None else "", "+u" if op["ups"] else "")
+        else:
+            flops, byt, shape = 0.0, 0.0, op["kind"]
+        ideal = max(flops / peak, byt / 6.3e12) * 1e3
+        tot += ms; tot_ideal += ideal
+        print("%3d %5d %-22s %9.4f %8.1f %8.0f %8.4f %6.1f%%" % (i, op["layer"], shape, ms, flops / ms / 1e9, byt / ms / 1e6,
+                                                                ideal, 100 * ideal / ms if ms else 0))
+    print("total %.3f ms   sum of per-launch rooflines %.3f ms (MFMA peak %.0f TF, HBM 6.3 TB/s achievable)" % (tot, tot_ideal, peak / 1e12))
+
+
+if __name__ == "__main__":
+    main()

@@ -189,11 +189,12 @@ class Network(object):
             self._plans[key] = cp
         return cp
 
-    def forward(self, images, chunk=None):
+    def forward(self, images, chunk=None, trace=None):
         """images: float32 NHWC [B,H,W,3] on this network's device, values as the reference
         feeds them (image/255, inference.py:242).  Returns the head tensors (fp32,
         [B,g,g,3*(C+5)] views, coarse -> fine).  `chunk` splits the batch into sub-batches
-        that run back to back through the whole plan."""
+        that run back to back through the whole plan.  `trace`, if a list, receives
+        (op, start_event, end_event) for every launch (HIP events on the launch stream)."""
         if not isinstance(images, torch.Tensor):
             images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
         if images.dim() != 4 or images.shape[-1] != 3:
@@ -211,10 +212,21 @@ class Network(object):
             cp = first if nb == step else self.plan_for(nb, H, W)
             env = {"in": in_base + b0 * H * W * 3 * 4, "stream": stream,
                    "heads": [h.data_ptr() + b0 * h.stride(0) * 4 for h in heads]}
-            for launch in cp.launchers:
-                rc = launch(env)
-                if rc:
-                    _lib.check(rc)
+            if trace is None:
+                for launch in cp.launchers:
+                    rc = launch(env)
+                    if rc:
+                        _lib.check(rc)
+            else:
+                for op, launch in zip(cp.plan.ops, cp.launchers):
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = launch(env)
+                    e1.record()
+                    if rc:
+                        _lib.check(rc)
+                    trace.append((op, e0, e1))
         self._keepalive = images
         return [h[..., :hd["c"]] for h, hd in zip(heads, first.plan.heads)]
 
