@@ -74,6 +74,9 @@ int y3_conv_weight_layout(y3_conv_desc *desc);
 int y3_conv2d_fused(const y3_conv_desc *desc, const void *in, const void *w, const float *bias,
                     const void *residual, void *out, const void *zeros, void *stream);
 
+/* Tuning knob for experiments: force the implicit-GEMM tile (0 = heuristic, 128, 256). Process-global. */
+int y3_set_conv_tile(int tile);
+
 /* tf.nn.max_pool(padding='SAME'), build_model.py:207-210.  c % (16/elsize) == 0. */
 int y3_maxpool2d(int dtype, const void *in, void *out, int batch, int in_h, int in_w, int c,
                  int in_ld, int out_ld, int size, int stride, void *stream);

@@ -130,3 +130,35 @@ def test_conv_rejects_bad_arguments():
     d.k_pad = 288
     assert lib.y3_conv2d_fused(ctypes.byref(d), p, p, p, None, p, p, None) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 38, 128, 256, 3, 1, True), (1, 19, 512, 1024, 3, 2, True), (3, 13, 256, 512, 1, 1, False),
+                                  (2, 20, 32, 256, 3, 1, True), (1, 9, 64, 128, 1, 1, True)],
+                         ids=str)
+def test_conv_tile256_equals_tile128(case, dtype):
+    """The 256x256-tile variant (8 waves, two epilogue passes) against the oracle and against
+    the 128x128 variant (same k order per output -> identical bits)."""
+    from yolo_amd import _lib
+    lib = _lib.load()
+    B, H, C, O, ks, stride, leaky = case
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((B, H, H, C)).astype(np.float32)
+    k = (rng.standard_normal((ks, ks, C, O)) * np.sqrt(2.0 / (ks * ks * C))).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32)
+    r = rng.standard_normal((B,) + _ref(x, k, b, stride, leaky).shape[1:]).astype(np.float32)
+    if dtype == "bf16":
+        x, k, r = gpu_util.bf16_round(x), gpu_util.bf16_round(k), gpu_util.bf16_round(r)
+    outs = {}
+    try:
+        # low half: tile; high half: experiment bits (4 = ring-pipelined main loop, 2 = no interleave)
+        for tile in (128, 256, (4 << 16) | 128, (4 << 16) | 256, (2 << 16) | 256):
+            _lib.check(lib.y3_set_conv_tile(tile))
+            outs[tile] = gpu_util.run_conv(x, k, b, stride, dtype, leaky=leaky, residual=r)
+    finally:
+        lib.y3_set_conv_tile(0)
+    want = _ref(x, k, b, stride, leaky, residual=r)
+    tol = 1e-3 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(want))
+    assert np.all(np.abs(outs[256] - want) <= tol)
+    for tile in outs:           # same k order per accumulator in every variant -> identical bits
+        np.testing.assert_array_equal(outs[128], outs[tile])

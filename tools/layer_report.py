@@ -21,8 +21,11 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--tile", type=int, default=0)
     a = ap.parse_args()
     cfg = config.yolov3_tiny_cfg_path if a.model == "yolov3-tiny" else config.yolov3_cfg_path
+    from yolo_amd import _lib
+    _lib.check(_lib.load().y3_set_conv_tile(a.tile))
     net = build_model.Network(cfg, 80, dtype=a.dtype)
     net.set_params(dw.random_params(net.layers, seed=0))
     x = torch.rand((a.batch, a.size, a.size, 3), device="cuda")

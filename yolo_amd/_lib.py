@@ -30,6 +30,7 @@ class DecodeDesc(ctypes.Structure):
 SIGNATURES = {
     "y3_conv_weight_layout": (c_int, [ctypes.POINTER(ConvDesc)]),
     "y3_conv2d_fused": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_set_conv_tile": (c_int, [c_int]),
     "y3_maxpool2d": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "y3_upsample2x": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "y3_copy_channels": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),

@@ -20,8 +20,18 @@
 // makes the ds_read_b128 fragment reads bank-conflict free.  Zero padding comes
 // from pointing the lane's source address at a zero page.
 #include "common.h"
+#include <type_traits>
 
 namespace {
+
+int g_conv_tile = 0;      // experiment knobs, see y3_set_conv_tile
+int g_conv_debug = 0;
+
+struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
+
+__device__ __forceinline__ int fast_div(int n, FastDiv d) {
+    return (int)((__umulhi((unsigned)n, d.magic) + (unsigned)n) >> d.shift);
+}
 
 struct ConvArgs {
     const char *in, *w, *res, *zeros;
@@ -29,8 +39,30 @@ struct ConvArgs {
     char *out;
     int H, W, Cin, in_ld;
     int Ho, Wo, HoWo, Cout8, out_ld, res_ld;
-    int ks, stride, pad, Kpad, M, n_tiles, flags, step_tap, step_cin;
+    int ks, stride, pad, Kpad, M, n_tiles, flags, step_tap, step_cin, sub_tap, sub_cin;
+    FastDiv fd_howo, fd_wo;
 };
+
+// Output row gm -> byte offset of its window's first input element and the 9-bit (1-bit for 1x1)
+// mask of taps that fall inside the image.  Branch-free; the two divisions are multiplications.
+__device__ __forceinline__ void row_setup(const ConvArgs &p, int gm, int es, long &base, unsigned &mask) {
+    const int b = fast_div(gm, p.fd_howo);
+    const int r = gm - b * p.HoWo;
+    const int ho = fast_div(r, p.fd_wo);
+    const int wo = r - ho * p.Wo;
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    base = (((long)b * p.H + hi0) * p.W + wi0) * (long)p.in_ld * es;
+    if (p.ks == 1) {
+        mask = ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) ? 1u : 0u;
+    } else {
+        unsigned vw = 0, m = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vw |= ((unsigned)(wi0 + k) < (unsigned)p.W ? 1u : 0u) << k;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m |= ((unsigned)(hi0 + k) < (unsigned)p.H ? vw : 0u) << (3 * k);
+        mask = m;
+    }
+}
 
 __device__ __forceinline__ int xcd_remap(int orig, int nblk) {
     // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
@@ -46,18 +78,128 @@ __device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
-    constexpr int ES = BF16 ? 2 : 4;          // element bytes
-    constexpr int EPC = 16 / ES;              // elements per 16-byte chunk
-    constexpr int BKE = 128 / ES;             // elements per k-step
+// Epilogue shared by the convolution kernels: accumulators -> LDS (fp32) -> bias, leaky, residual ->
+// NHWC rows with 16-byte stores, EP_ROWS tile rows per pass.
+template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI][MI], char *smem, int m0, int n0,
+                                              int tid, int wm, int wn) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int ES = BF16 ? 2 : 4;
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
+    constexpr int CS_LD = BN + 4;
+    const int lane = tid & 63;
+    const int frow = lane & 15, fq = lane >> 4;
+    float *Cs = (float *)smem;
+    constexpr int NCH = BN / 8;
+    constexpr int O_IT = EP_ROWS * NCH / NT;
+    static_assert(EP_ROWS * NCH % NT == 0, "epilogue chunks vs threads");
+    const bool leaky = p.flags & Y3_CONV_LEAKY;
+    const bool has_res = p.flags & Y3_CONV_RESIDUAL;
+    const bool ups = p.flags & Y3_CONV_UPS2X;
+    const bool out_f32 = !BF16 || (p.flags & Y3_CONV_OUT_F32);
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+        // residual operand: all of this pass's loads go out before the LDS round trip, so their
+        // latency hides under it instead of serialising the store loop.
+        u32x4 rv[O_IT][BF16 ? 1 : 2];
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < O_IT; ++i) {
+                const int q = tid + NT * i;
+                const int row = q / NCH, ch = q % NCH;
+                const int gm = m0 + pass * EP_ROWS + row, n = n0 + ch * 8;
+                const bool ok = gm < p.M && n < p.Cout8;
+                const char *rp = ok ? p.res + ((long)gm * p.res_ld + n) * ES : p.zeros;
+                rv[i][0] = *(const u32x4 *)rp;
+                if constexpr (!BF16) rv[i][1] = *(const u32x4 *)(rp + 16);
+            }
+        }
+        __syncthreads();                       // LDS tiles / previous pass fully consumed
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int rb = wm * TM + mi * 16 - pass * EP_ROWS;       // wave-uniform
+            if (rb < 0 || rb >= EP_ROWS) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = wn * TN + ni * 16 + fq * 4;
+                *(f32x4 *)(Cs + (rb + frow) * CS_LD + n) = acc[ni][mi];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < O_IT; ++i) {
+            const int q = tid + NT * i;
+            const int row = q / NCH, ch = q % NCH;
+            const int gm = m0 + pass * EP_ROWS + row, n = n0 + ch * 8;
+            if (gm >= p.M || n >= p.Cout8) continue;
+            f32x4 v0 = *(const f32x4 *)(Cs + row * CS_LD + ch * 8);
+            f32x4 v1 = *(const f32x4 *)(Cs + row * CS_LD + ch * 8 + 4);
+            v0 += *(const f32x4 *)(p.bias + n);
+            v1 += *(const f32x4 *)(p.bias + n + 4);
+            if (leaky) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v0[j] = leaky01(v0[j]); v1[j] = leaky01(v1[j]); }
+            }
+            if (has_res) {
+                if constexpr (BF16) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        v0[2 * j] += bf16_to_f32(rv[i][0][j] & 0xffff);
+                        v0[2 * j + 1] += bf16_to_f32(rv[i][0][j] >> 16);
+                        v1[2 * j] += bf16_to_f32(rv[i][0][2 + j] & 0xffff);
+                        v1[2 * j + 1] += bf16_to_f32(rv[i][0][2 + j] >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v0[j] += __uint_as_float(rv[i][0][j]);
+                        v1[j] += __uint_as_float(rv[i][1][j]);
+                    }
+                }
+            }
+            long opix = gm;
+            long row2 = 0;
+            if (ups) {
+                const int b = fast_div(gm, p.fd_howo);
+                const int r = gm - b * p.HoWo;
+                const int ho = fast_div(r, p.fd_wo);
+                const int wo = r - ho * p.Wo;
+                row2 = 2L * p.Wo;
+                opix = ((long)b * 2 * p.Ho + 2 * ho) * row2 + 2 * wo;
+            }
+            const int reps = ups ? 4 : 1;
+            for (int rpt = 0; rpt < reps; ++rpt) {
+                const long pix = opix + (rpt & 1) + (rpt >> 1) * row2;
+                if (out_f32) {
+                    float *op = (float *)p.out + pix * p.out_ld + n;
+                    *(f32x4 *)op = v0;
+                    *(f32x4 *)(op + 4) = v1;
+                } else {
+                    u32x4 o;
+                    o[0] = pack_bf16x2(v0[0], v0[1]);
+                    o[1] = pack_bf16x2(v0[2], v0[3]);
+                    o[2] = pack_bf16x2(v1[0], v1[1]);
+                    o[3] = pack_bf16x2(v1[2], v1[3]);
+                    *(u32x4 *)(p.out + (pix * p.out_ld + n) * 2) = o;
+                }
+            }
+        }
+    }
+}
+
+template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, bool INTERLEAVE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;   // threads
+    constexpr int ES = BF16 ? 2 : 4;             // element bytes
+    constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
+    constexpr int BKE = 128 / ES;                // elements per k-step
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
     constexpr int MI = TM / 16, NI = TN / 16;
-    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
-    constexpr int STAGE = (BM + BN) * 128;    // bytes per pipeline buffer
-    constexpr int CS_LD = BN + 4;             // floats per staged output row
-    static_assert(WAVES_M * WAVES_N == 4, "256 threads");
-    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the loader");
+    constexpr int LROWS = NT / 8;                // tile rows one loader pass covers
+    constexpr int A_IT = BM / LROWS, B_IT = BN / LROWS;
+    constexpr int PIECE = NT * 16;               // bytes one loader pass writes
+    constexpr int STAGE = (BM + BN) * 128;       // bytes per pipeline buffer
+    static_assert(BM % LROWS == 0 && BN % LROWS == 0, "tile vs loader");
+    static_assert(BM % EP_ROWS == 0 && EP_ROWS % 16 == 0 && TM % 16 == 0, "epilogue passes");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -70,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // ---- loader set-up: thread owns LDS chunk slot (tid&7) of rows (tid>>3)+32i --------
+    // ---- loader set-up: thread owns LDS chunk slot (tid&7) of rows (tid>>3) + LROWS*i --------
     const int lrow = tid >> 3;
     const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * EPC;   // source chunk of this LDS slot
 
@@ -78,53 +220,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     unsigned a_mask[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int gm = m0 + lrow + 32 * i;
+        const int gm = m0 + lrow + LROWS * i;
         a_base[i] = 0;
         a_mask[i] = 0;
-        if (gm < p.M) {
-            const int b = gm / p.HoWo;
-            const int r = gm - b * p.HoWo;
-            const int ho = r / p.Wo;
-            const int wo = r - ho * p.Wo;
-            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-            a_base[i] = (((long)b * p.H + hi0) * p.W + wi0) * (long)p.in_ld * ES;
-            unsigned mask = 0;
-            for (int kh = 0; kh < p.ks; ++kh)
-                for (int kw = 0; kw < p.ks; ++kw)
-                    if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
-                        mask |= 1u << (kh * p.ks + kw);
-            a_mask[i] = mask;
-        }
+        if (gm < p.M) row_setup(p, gm, ES, a_base[i], a_mask[i]);
     }
     long w_off[B_IT];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) w_off[i] = ((long)(n0 + lrow + 32 * i) * p.Kpad + kc) * ES;
+    for (int i = 0; i < B_IT; ++i) w_off[i] = ((long)(n0 + lrow + LROWS * i) * p.Kpad + kc) * ES;
 
     // k position of this thread's chunk: tap = k / Cin, cin = k % Cin, advanced by BKE per k-step
     // without a division (step_tap = BKE / Cin, step_cin = BKE % Cin come from the host).
     int tap = kc / p.Cin;
     int cin = kc - tap * p.Cin;
 
-    auto stage = [&](int kt, int buf) {
+    // One k-step of loads is NP = A_IT + B_IT LDS-DMA pieces (1 KiB per wave each).  An LDS-DMA
+    // instruction holds the issuing wave for ~60-180 cycles, so the pieces are not issued in a
+    // burst after the barrier (the MFMA pipe would idle behind it): they are spread between
+    // the MFMAs of the first half of the k-step, and land during the second half.
+    constexpr int NP = A_IT + B_IT;
+    constexpr int NMF = NI * MI;                 // MFMA groups per 32-deep half step
+    long toff = 0;
+    int tapc = 0;
+    auto stage_begin = [&]() {
         // a_mask has no bit at or above ks*ks, so padded k (tap >= ks*ks) reads the zero page too.
         const int th = p.ks == 3 ? (tap * 11) >> 5 : tap;          // tap / 3 for tap < 16
         const int tw = tap - th * p.ks;
-        const long toff = ((long)(th * p.W + tw) * p.in_ld + cin) * ES;
-        char *abase = smem + buf * STAGE + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const char *cand = p.in + (a_base[i] + toff);
-            const char *src = ((a_mask[i] >> tap) & 1u) ? cand : p.zeros;
-            glds16(src, abase + i * 4096);
-        }
-        char *bbase = abase + BM * 128;
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(p.w + w_off[i] + (long)kt * 128, bbase + i * 4096);
+        toff = ((long)(th * p.W + tw) * p.in_ld + cin) * ES;
+        tapc = tap;
         tap += p.step_tap;
         cin += p.step_cin;
         const bool wrap = cin >= p.Cin;
         cin = wrap ? cin - p.Cin : cin;
         tap = wrap ? tap + 1 : tap;
+    };
+    const bool skip_a = p.flags & (1 << 29), skip_b = p.flags & (1 << 28);
+    auto piece = [&](int q, int kt, int buf) {
+        char *base = smem + buf * STAGE + wave * 1024;
+        if (q < A_IT ? skip_a : skip_b) return;
+        if (q < A_IT) {
+            const char *cand = p.in + (a_base[q] + toff);
+            const char *src = ((a_mask[q] >> tapc) & 1u) ? cand : p.zeros;
+            glds16(src, base + q * PIECE);
+        } else {
+            glds16(p.w + w_off[q - A_IT] + (long)kt * 128, base + BM * 128 + (q - A_IT) * PIECE);
+        }
     };
 
     // ---- main loop ------------------------------------------------------------------------
@@ -139,123 +279,211 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int fq = lane >> 4;
     const int nk = p.Kpad / BKE;
 
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    auto kstep = [&](int kt, auto prefetch) {
+        constexpr bool PF = decltype(prefetch)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of tile kt has landed
         __syncthreads();                                    // everyone's has; buffer (kt+1)&1 is free
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        if constexpr (PF) stage_begin();
         const char *As = smem + (kt & 1) * STAGE;
         const char *Bs = As + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int so = ((ks * 4 + fq) ^ fsw) * 16;
-            if constexpr (BF16) {
-                bf16x8 xf[MI], wf[NI];
+            using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
+            frag_t xf[MI], wf[NI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    xf[mi] = *(const bf16x8 *)(As + (wm * TM + mi * 16 + frow) * 128 + so);
+            for (int mi = 0; mi < MI; ++mi)
+                xf[mi] = *(const frag_t *)(As + (wm * TM + mi * 16 + frow) * 128 + so);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    wf[ni] = *(const bf16x8 *)(Bs + (wn * TN + ni * 16 + frow) * 128 + so);
+            for (int ni = 0; ni < NI; ++ni)
+                wf[ni] = *(const frag_t *)(Bs + (wn * TN + ni * 16 + frow) * 128 + so);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+            for (int j = 0; j < NMF; ++j) {
+                if constexpr (PF) {
+                    if (ks == 0) {
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-            } else {
-                f32x4 xf[MI], wf[NI];
+                        for (int q = 0; q < NP; ++q)
+                            if (j == (q * NMF) / NP) {
+                                if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+                                piece(q, kt + 1, (kt + 1) & 1);
+                                if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
+                }
+                const int ni = j / MI, mi = j % MI;
+                if constexpr (BF16) {
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+                } else {
+                    // lane group g holds k = 4g..4g+3 of this 16-wide k block: MFMA i sums k = 4g+i over g.
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    xf[mi] = *(const f32x4 *)(As + (wm * TM + mi * 16 + frow) * 128 + so);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    wf[ni] = *(const f32x4 *)(Bs + (wn * TN + ni * 16 + frow) * 128 + so);
-                // lane group g holds k = 4g..4g+3 of this 16-wide k block: MFMA j sums k = 4g+j over g.
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-                            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][j], xf[mi][j], acc[ni][mi], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][i], xf[mi][i], acc[ni][mi], 0, 0, 0);
+                }
             }
         }
-    }
+    };
 
-    // ---- epilogue: accumulators -> LDS (fp32) -> bias, leaky, residual -> NHWC rows ----------
-    __syncthreads();
-    float *Cs = (float *)smem;
+    stage_begin();
+#pragma unroll
+    for (int q = 0; q < NP; ++q) piece(q, 0, 0);
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
+    kstep(nk - 1, std::false_type{});
+
+    conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI>(p, acc, smem, m0, n0, tid, wm, wn);
+}
+
+// ---- ring-pipelined variant -------------------------------------------------------------------
+// Same GEMM view and epilogue, different main loop: the LDS holds a ring of RING sub-tiles,
+// each one 32 bf16 (16 fp32) deep = one 64-byte row per pixel / channel.  LDS-DMA loads run
+// RING-1 sub-steps ahead and are retired with a COUNTED s_waitcnt vmcnt(N) + a raw s_barrier, so
+// loads stay in flight across barriers instead of being drained once per k-step (the 2-stage
+// kernel above spends ~40 % of its wave cycles in that drain: SQ_WAIT_ANY, profiles/).
+// 64-byte rows: four rows share a 256-byte bank row, chunk c of row r sits at slot
+// c ^ (3 * ((r >> 2) & 1)), which keeps the ds_read_b128 fragment reads conflict free.
+template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, int RING>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_ring_kernel(const ConvArgs p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int ES = BF16 ? 2 : 4;
+    constexpr int EPC = 16 / ES;
+    constexpr int BKS = 64 / ES;                 // elements per sub-step
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int LROWS = NT / 4;                // tile rows one loader pass covers (4 chunks a row)
+    constexpr int A_IT = BM / LROWS, B_IT = BN / LROWS;
+    constexpr int NP = A_IT + B_IT;              // LDS-DMA pieces per thread per sub-step
+    constexpr int PIECE = NT * 16;
+    constexpr int SLOT = (BM + BN) * 64;         // bytes per ring slot
+    constexpr int NMF = NI * MI;
+    static_assert(BM % LROWS == 0 && BN % LROWS == 0 && LROWS % 16 == 0, "tile vs loader");
+    static_assert(RING == 4, "wait counts below are written for a 4-slot ring");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // loader: thread owns LDS slot (tid&3) of rows (tid>>2) + LROWS*i
+    const int lrow = tid >> 2;
+    const int kc = ((tid & 3) ^ (3 * ((tid >> 4) & 1))) * EPC;
+
+    long a_base[A_IT];
+    unsigned a_mask[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int gm = m0 + lrow + LROWS * i;
+        a_base[i] = 0;
+        a_mask[i] = 0;
+        if (gm < p.M) row_setup(p, gm, ES, a_base[i], a_mask[i]);
+    }
+    long w_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) w_off[i] = ((long)(n0 + lrow + LROWS * i) * p.Kpad + kc) * ES;
+
+    int tap = kc / p.Cin;
+    int cin = kc - tap * p.Cin;
+    long toff = 0;
+    int tapc = 0;
+    auto stage_begin = [&]() {
+        const int th = p.ks == 3 ? (tap * 11) >> 5 : tap;
+        const int tw = tap - th * p.ks;
+        toff = ((long)(th * p.W + tw) * p.in_ld + cin) * ES;
+        tapc = tap;
+        tap += p.sub_tap;
+        cin += p.sub_cin;
+        const bool wrap = cin >= p.Cin;
+        cin = wrap ? cin - p.Cin : cin;
+        tap = wrap ? tap + 1 : tap;
+    };
+    auto piece = [&](int q, int s, char *slot) {           // sub-tile s -> ring slot
+        char *base = slot + wave * 1024;
+        if (q < A_IT) {
+            const char *cand = p.in + (a_base[q] + toff);
+            const char *src = ((a_mask[q] >> tapc) & 1u) ? cand : p.zeros;
+            glds16(src, base + q * PIECE);
+        } else {
+            glds16(p.w + w_off[q - A_IT] + (long)s * 64, base + BM * 64 + (q - A_IT) * PIECE);
+        }
+    };
+
+    f32x4 acc[NI][MI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int m = wm * TM + mi * 16 + frow;
-            const int n = wn * TN + ni * 16 + fq * 4;
-            *(f32x4 *)(Cs + m * CS_LD + n) = acc[ni][mi];
-        }
-    __syncthreads();
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int NCH = BN / 8;
-    constexpr int O_IT = BM * NCH / 256;
-    const bool leaky = p.flags & Y3_CONV_LEAKY;
-    const bool has_res = p.flags & Y3_CONV_RESIDUAL;
-    const bool ups = p.flags & Y3_CONV_UPS2X;
-    const bool out_f32 = !BF16 || (p.flags & Y3_CONV_OUT_F32);
+    const int frow = lane & 15;
+    const int fq = lane >> 4;
+    const int so = (fq ^ (3 * ((lane >> 2) & 1))) * 16;     // this lane's chunk slot in a 64-byte row
+    const int ns = p.Kpad / BKS;
+
+    // prologue: sub-tiles 0 .. RING-2 in flight
 #pragma unroll
-    for (int i = 0; i < O_IT; ++i) {
-        const int q = tid + 256 * i;
-        const int row = q / NCH, ch = q % NCH;
-        const int gm = m0 + row, n = n0 + ch * 8;
-        if (gm >= p.M || n >= p.Cout8) continue;
-        f32x4 v0 = *(const f32x4 *)(Cs + row * CS_LD + ch * 8);
-        f32x4 v1 = *(const f32x4 *)(Cs + row * CS_LD + ch * 8 + 4);
-        v0 += *(const f32x4 *)(p.bias + n);
-        v1 += *(const f32x4 *)(p.bias + n + 4);
-        if (leaky) {
+    for (int s = 0; s < RING - 1; ++s) {
+        if (s < ns) {
+            stage_begin();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v0[j] = leaky01(v0[j]); v1[j] = leaky01(v1[j]); }
-        }
-        if (has_res) {
-            const char *rp = p.res + ((long)gm * p.res_ld + n) * ES;
-            if constexpr (BF16) {
-                const bf16x8 r = *(const bf16x8 *)rp;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v0[j] += bf16_to_f32((unsigned short)r[j]);
-                    v1[j] += bf16_to_f32((unsigned short)r[j + 4]);
-                }
-            } else {
-                v0 += *(const f32x4 *)rp;
-                v1 += *(const f32x4 *)(rp + 16);
-            }
-        }
-        long opix = gm;
-        long row2 = 0;
-        if (ups) {
-            const int b = gm / p.HoWo;
-            const int r = gm - b * p.HoWo;
-            const int ho = r / p.Wo;
-            const int wo = r - ho * p.Wo;
-            row2 = 2L * p.Wo;
-            opix = ((long)b * 2 * p.Ho + 2 * ho) * row2 + 2 * wo;
-        }
-        const int reps = ups ? 4 : 1;
-        for (int rpt = 0; rpt < reps; ++rpt) {
-            const long pix = opix + (rpt & 1) + (rpt >> 1) * row2;
-            if (out_f32) {
-                float *op = (float *)p.out + pix * p.out_ld + n;
-                *(f32x4 *)op = v0;
-                *(f32x4 *)(op + 4) = v1;
-            } else {
-                u32x4 o;
-                o[0] = pack_bf16x2(v0[0], v0[1]);
-                o[1] = pack_bf16x2(v0[2], v0[3]);
-                o[2] = pack_bf16x2(v1[0], v1[1]);
-                o[3] = pack_bf16x2(v1[2], v1[3]);
-                *(u32x4 *)(p.out + (pix * p.out_ld + n) * 2) = o;
-            }
+            for (int q = 0; q < NP; ++q) piece(q, s, smem + s * SLOT);
         }
     }
+
+    int rd = 0;                 // ring slot of sub-tile s
+    int wr = RING - 1;          // ring slot sub-tile s + RING - 1 goes to
+    for (int s = 0; s < ns; ++s) {
+        // this wave's pieces of sub-tile s have landed once at most the younger sub-tiles' remain
+        const int ahead = ns - 1 - s;
+        if (ahead >= 2) {
+            if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (ahead == 1) {
+            if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();      // everyone's pieces of s landed; slot wr (read in s-1) is free
+        const bool pf = s + RING - 1 < ns;
+        if (pf) stage_begin();
+        const char *As = smem + rd * SLOT;
+        const char *Bs = As + BM * 64;
+        char *wslot = smem + wr * SLOT;
+        using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
+        frag_t xf[MI], wf[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const frag_t *)(As + (wm * TM + mi * 16 + frow) * 64 + so);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const frag_t *)(Bs + (wn * TN + ni * 16 + frow) * 64 + so);
+#pragma unroll
+        for (int j = 0; j < NMF; ++j) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                if (j == (q * NMF) / NP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pf) piece(q, s + RING - 1, wslot);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            const int ni = j / MI, mi = j % MI;
+            if constexpr (BF16) {
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][i], xf[mi][i], acc[ni][mi], 0, 0, 0);
+            }
+        }
+        rd = rd + 1 == RING ? 0 : rd + 1;
+        wr = wr + 1 == RING ? 0 : wr + 1;
+    }
+    conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI>(p, acc, smem, m0, n0, tid, wm, wn);
 }
 
 // ---- direct convolution: first layer (Cin = 3) and any Cin the chunked loader cannot take ----
@@ -321,12 +549,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirectArgs p) {
     }
 }
 
-template <bool BF16, int BM, int BN, int WM, int WN>
-int launch_igemm(const ConvArgs &a, hipStream_t stream) {
+template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS, bool IL>
+int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
     constexpr int stage_bytes = 2 * (BM + BN) * 128;
-    constexpr int cs_bytes = BM * (BN + 4) * 4;
+    constexpr int cs_bytes = EP_ROWS * (BN + 4) * 4;
     constexpr int lds = stage_bytes > cs_bytes ? stage_bytes : cs_bytes;
-    auto kern = conv_igemm_kernel<BF16, BM, BN, WM, WN>;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv_igemm_kernel<BF16, BM, BN, WM, WN, EP_ROWS, IL>;
+    a.n_tiles = n_pad / BN;
     static thread_local int attr_dev = -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -340,8 +570,50 @@ int launch_igemm(const ConvArgs &a, hipStream_t stream) {
     const int m_tiles = (a.M + BM - 1) / BM;
     const long nblk = (long)m_tiles * a.n_tiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv: grid of %ld blocks", nblk); return Y3_E_INVALID; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, a);
     return y3_check_launch("conv_igemm");
+}
+
+
+template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS>
+int launch_ring(ConvArgs a, int n_pad, hipStream_t stream) {
+    constexpr int RING = 4;
+    constexpr int ring_bytes = RING * (BM + BN) * 64;
+    constexpr int cs_bytes = EP_ROWS * (BN + 4) * 4;
+    constexpr int lds = ring_bytes > cs_bytes ? ring_bytes : cs_bytes;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv_igemm_ring_kernel<BF16, BM, BN, WM, WN, EP_ROWS, RING>;
+    a.n_tiles = n_pad / BN;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            y3_set_error("conv: cannot reserve %d bytes of LDS", lds);
+            return Y3_E_LAUNCH;
+        }
+        attr_dev = dev;
+    }
+    const int m_tiles = (a.M + BM - 1) / BM;
+    const long nblk = (long)m_tiles * a.n_tiles;
+    if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv: grid of %ld blocks", nblk); return Y3_E_INVALID; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, a);
+    return y3_check_launch("conv_igemm_ring");
+}
+
+template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS>
+int launch_igemm(const ConvArgs &a, int n_pad, hipStream_t stream) {
+    if (g_conv_debug & 2) return launch_igemm_<BF16, BM, BN, WM, WN, EP_ROWS, false>(a, n_pad, stream);
+    return launch_igemm_<BF16, BM, BN, WM, WN, EP_ROWS, true>(a, n_pad, stream);
+}
+
+inline FastDiv make_fastdiv(int d) {
+    unsigned shift = 0;
+    while ((1ull << shift) < (unsigned long long)d) ++shift;
+    FastDiv f;
+    f.magic = (unsigned)((((1ull << 32) * ((1ull << shift) - (unsigned long long)d)) / (unsigned long long)d) + 1);
+    f.shift = shift;
+    return f;
 }
 
 inline int bn_for(int out_c) { return out_c > 64 ? 128 : (out_c > 32 ? 64 : 32); }
@@ -434,17 +706,49 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     a.Ho = d->out_h; a.Wo = d->out_w; a.HoWo = d->out_h * d->out_w; a.Cout8 = cout8;
     a.out_ld = d->out_ld; a.res_ld = d->res_ld;
     a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.Kpad = d->k_pad; a.M = (int)M; a.flags = d->flags;
+    if (g_conv_debug & 1) a.H = 0;             // timing experiment: every A tap reads the zero page
+    if (g_conv_debug & 8) a.flags |= 1 << 29;  // timing experiment: no A loads at all (garbage results)
+    if (g_conv_debug & 16) a.flags |= 1 << 28; // timing experiment: no B loads at all (garbage results)
     const int bn = bn_for(d->out_c);
-    a.n_tiles = d->n_pad / bn;
     const int bke = bf16 ? 64 : 32;
+    a.n_tiles = 0;
     a.step_tap = bke / d->in_c;
     a.step_cin = bke % d->in_c;
-    if (bf16) {
-        if (bn == 128) return launch_igemm<true, 128, 128, 2, 2>(a, stream);
-        if (bn == 64) return launch_igemm<true, 128, 64, 2, 2>(a, stream);
-        return launch_igemm<true, 128, 32, 4, 1>(a, stream);
+    a.fd_howo = make_fastdiv(a.HoWo);
+    a.fd_wo = make_fastdiv(a.Wo);
+    a.sub_tap = (bke / 2) / d->in_c;
+    a.sub_cin = (bke / 2) % d->in_c;
+    // Tile choice.  L2 -> LDS bytes per FLOP fall with the tile area, so compute-bound layers (3x3,
+    // Cout a multiple of 256) take the 256x256 tile; everything else the 128-row tiles.
+    int tile = g_conv_tile;
+    if (tile == 0) tile = (bn == 128 && d->n_pad % 256 == 0 && d->ksize == 3 && M >= 256 * 256) ? 256 : 128;
+    if (tile == 256 && !(bn == 128 && d->n_pad % 256 == 0)) tile = 128;
+    if (g_conv_debug & 4) {            // ring-pipelined kernels (experiment switch)
+        if (bf16) {
+            if (bn == 128 && tile == 256) return launch_ring<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+            if (bn == 128) return launch_ring<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
+        } else {
+            if (bn == 128 && tile == 256) return launch_ring<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+            if (bn == 128) return launch_ring<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
+        }
     }
-    if (bn == 128) return launch_igemm<false, 128, 128, 2, 2>(a, stream);
-    if (bn == 64) return launch_igemm<false, 128, 64, 2, 2>(a, stream);
-    return launch_igemm<false, 128, 32, 4, 1>(a, stream);
+    if (bf16) {
+        if (bn == 128 && tile == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+        if (bn == 128) return launch_igemm<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
+        if (bn == 64) return launch_igemm<true, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
+        return launch_igemm<true, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
+    }
+    if (bn == 128 && tile == 256) return launch_igemm<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+    if (bn == 128) return launch_igemm<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
+    if (bn == 64) return launch_igemm<false, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
+    return launch_igemm<false, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
+}
+
+// Experiment knob (not part of the stable ABI contract): force the conv tile (0 = heuristic).
+extern "C" int y3_set_conv_tile(int tile) {
+    g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
+    tile &= 0xffff;
+    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 256, Y3_E_INVALID, "conv tile %d (0, 128 or 256)", tile);
+    g_conv_tile = tile;
+    return Y3_OK;
 }
