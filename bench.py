@@ -8,7 +8,7 @@ One step = one pass of the hot path over one batch of synthetic input that is al
 resident in HBM: 64 images of 608x608x3 per GPU (BASELINE.json configs[3]), seeded
 random-init Darknet-53 weights, bf16 compute.  Ranks shard the global batch by image
 (no data-path collective); rank 0 prints ONE JSON line.  `roofline` prices the dominant
-kernel (the 128x128-tile bf16 implicit-GEMM convolution) against the dense bf16 MFMA peak
+kernel (the bf16 implicit-GEMM convolution variant most of the step's time goes to) against the dense bf16 MFMA peak
 from HIP-event timings taken inside the timed region; `cpu_baseline` times the numpy/C
 oracle (a CPU restatement, NOT TensorFlow) on the host cores for a bounded sample.
 """
@@ -52,12 +52,6 @@ def parse_args():
 def conv_flops(op, batch):
     oh, ow = op["out_hw"]
     return 2.0 * batch * oh * ow * op["out_c"] * op["ksize"] ** 2 * op["in_c"]
-
-
-def is_dominant(op, dtype):
-    """The launches that run conv_igemm_kernel<bf16, 128, 128, 2, 2> (Cout > 64, chunked Cin)."""
-    epc = 8 if dtype == "bf16" else 4
-    return op["kind"] == "conv" and op["out_c"] > 64 and op["in_c"] % epc == 0 and not op["in_f32"]
 
 
 def cpu_baseline(model_cfg, size, n_images, score_threshold):
@@ -161,24 +155,37 @@ def main():
         }
         if traces:
             nb = chunk or (hi - lo)
-            dom_ms, dom_flops, dom_n, conv_ms, other_ms = 0.0, 0.0, 0, 0.0, 0.0
+            per_kernel = {}          # rocprof kernel name -> [ms, flops, launches]
+            conv_ms = other_ms = 0.0
             for tr in traces:
                 for op, e0, e1 in tr:
                     ms = e0.elapsed_time(e1)
-                    if is_dominant(op, args.dtype):
-                        dom_ms += ms; dom_flops += conv_flops(op, nb); dom_n += 1
                     if op["kind"] == "conv":
                         conv_ms += ms
+                        k = per_kernel.setdefault(op["kernel"], [0.0, 0.0, 0])
+                        k[0] += ms; k[1] += conv_flops(op, nb); k[2] += 1
                     else:
                         other_ms += ms
             peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-            achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+            dom = max(per_kernel, key=lambda k: per_kernel[k][0])          # the kernel most time goes to
+            dom_ms, dom_flops, dom_n = per_kernel[dom]
+            achieved = dom_flops / (dom_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": None,
-                               "kernel": "conv_igemm_kernel<%s,128,128,2,2>" % args.dtype,
-                               "launches_per_step": dom_n // len(traces),
-                               "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
-                               "avg_gflop_per_launch": round(dom_flops / max(dom_n, 1) / 1e9, 3)}
+                               "kernel": dom + ">", "launches_per_step": dom_n // len(traces),
+                               "avg_launch_ms": round(dom_ms / dom_n, 4),
+                               "avg_gflop_per_launch": round(dom_flops / dom_n / 1e9, 3),
+                               "share_of_step": round(dom_ms / len(traces) / (1e3 * elapsed / args.steps), 3)}
+            try:            # HBM bytes per launch of that kernel, from the committed PMC passes (profiles/)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                for name, byt in tj["hbm_bytes_per_launch"].items():
+                    if name.startswith(dom):
+                        out["roofline"]["traffic"] = byt
+                        out["roofline"]["traffic_source"] = tj["source"]
+            except (OSError, ValueError, KeyError):
+                pass
+            out["kernels"] = {k + ">": {"ms_per_step": round(v[0] / len(traces), 3), "launches_per_step": v[2] // len(traces),
+                                        "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in per_kernel.items()}
             out["stage_ms_per_step"] = {"conv_all": round(conv_ms / len(traces), 3),
                                         "other_layers": round(other_ms / len(traces), 3),
                                         "decode_nms_pack_and_gaps": round(1e3 * elapsed / args.steps - (conv_ms + other_ms) / len(traces), 3)}

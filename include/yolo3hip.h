@@ -74,6 +74,9 @@ int y3_conv_weight_layout(y3_conv_desc *desc);
 int y3_conv2d_fused(const y3_conv_desc *desc, const void *in, const void *w, const float *bias,
                     const void *residual, void *out, const void *zeros, void *stream);
 
+/* Name (prefix) of the kernel a descriptor will run on, as rocprofv3 reports it. Host-only. */
+int y3_conv_kernel_name(const y3_conv_desc *desc, char *buf, int len);
+
 /* Tuning knob for experiments: force the implicit-GEMM tile (0 = heuristic, 128, 256). Process-global. */
 int y3_set_conv_tile(int tile);
 
@@ -152,6 +155,10 @@ int y3_nms_lds_bytes(int boxes_per_image);
 int y3_pack_outputs(const float *records, const int32_t *kept_idx, const int32_t *kept_count, int batch,
                     int boxes_per_image, int num_classes, int max_boxes, float *out_boxes,
                     float *out_scores, int32_t *out_classes, int32_t *out_count, void *stream);
+
+/* Network input staging: fp32 [pixels][cin] (cin <= 8 bf16 / 4 fp32) -> dtype [pixels][one 16-byte chunk],
+ * zero padded, so that the first convolution (cin = 3, build_model.py:86) runs on the MFMA kernel. */
+int y3_pad_input(int dtype, const float *in, void *out, int64_t pixels, int cin, void *stream);
 
 /* fp32 -> bf16 round-to-nearest-even on device (weight/activation staging). */
 int y3_cast_f32_to_bf16(const float *in, void *out, int64_t n, void *stream);

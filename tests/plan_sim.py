@@ -61,6 +61,8 @@ class Sim(object):
                         cols.append(xp[:, kh:kh + (oh - 1) * st + 1:st, kw:kw + (ow - 1) * st + 1:st, :])
                 a = np.concatenate(cols, axis=-1).reshape(B * oh * ow, ks * ks * ic)
                 w, bias = self.w[op["layer"]]
+                if w.shape[1] != ks * ks * ic:          # first layer: input channels zero-padded to one chunk
+                    w = np.pad(w.reshape(oc, ks * ks, -1), ((0, 0), (0, 0), (0, ic - w.shape[1] // (ks * ks)))).reshape(oc, -1)
                 y = a @ w.T + bias
                 if op["leaky"]:
                     y = np.where(y > 0, y, np.float32(0.1) * y)
@@ -75,6 +77,11 @@ class Sim(object):
                             self.write(op["y"], (b * 2 * oh + 2 * ho + dy) * 2 * ow + 2 * wo + dx, y)
                 else:
                     self.write(op["y"], np.arange(B * oh * ow), y)
+            elif k == "padin":
+                x = self.read(op["x"], op["pixels"])
+                y = np.zeros((op["pixels"], op["y"]["c"]), dtype=np.float32)
+                y[:, :op["c"]] = x
+                self.write(op["y"], np.arange(op["pixels"]), y)
             elif k == "maxpool":
                 ih, iw = op["in_hw"]; c, s, z = op["c"], op["stride"], op["size"]
                 oh, ow = -(-ih // s), -(-iw // s)

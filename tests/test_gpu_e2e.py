@@ -175,3 +175,19 @@ def test_missing_weights_raise_and_nothing_is_fetched(tmp_path):
         nodes(torch.zeros((1, 416, 416, 3)))
     with pytest.raises(ValueError):
         build_model.yolo(None, True, config.yolov3_tiny_cfg_path, 80)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_direct_first_layer_equals_padded_mfma_first_layer(dtype):
+    """The first conv runs either on the direct kernel (fp32 image, Cin=3) or, by default, on the
+    MFMA kernel over the zero-padded staged image: both must satisfy the head tolerance."""
+    layers, oi = od.parse_layers(config.yolov3_tiny_cfg_path, 80)
+    params = dw.random_params(layers, seed=6)
+    x = np.random.default_rng(6).random((2, 416, 416, 3), dtype=np.float32)
+    ref = od.forward(layers, oi, params, x)
+    for pad in (True, False):
+        net = build_model.Network(config.yolov3_tiny_cfg_path, 80, dtype=dtype, pad_input=pad)
+        net.set_params(params)
+        for h, r in zip(net(torch.from_numpy(x)), ref):
+            err = np.abs(h.cpu().numpy() - r).max()
+            assert err <= 1e-3 if dtype == "fp32" else err / np.abs(r).max() <= 2e-2

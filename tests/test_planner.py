@@ -10,13 +10,13 @@ from yolo_amd import config, planner
 from yolo_amd import darknet_weights as dw
 
 
-def _check(cfg, size, batch, fuse):
+def _check(cfg, size, batch, fuse, pad_input=False):
     layers, oi = planner.parse_cfg(cfg, 80)
     ol, ooi = od.parse_layers(cfg, 80)
     params = dw.random_params(layers, seed=11)
     x = np.random.default_rng(1).random((batch, size, size, 3), dtype=np.float32)
     ref = od.forward(ol, ooi, params, x)
-    plan = planner.build_plan(layers, oi, batch, size, size, "fp32", fuse=fuse)
+    plan = planner.build_plan(layers, oi, batch, size, size, "fp32", fuse=fuse, pad_input=pad_input)
     out = plan_sim.Sim(plan, layers, params, x).run()
     for a, b in zip(out, ref):
         assert a.shape == b.shape
@@ -73,3 +73,18 @@ def test_layer_walk_quirks():
     shapes = planner.infer_shapes(layers, 416, 416)
     assert shapes[11] == (13, 13, 512) and shapes[10] == (13, 13, 512)       # maxpool size 2 stride 1, SAME
     assert shapes[20] == (26, 26, 384)
+
+
+def test_direct_first_layer_plan_still_available():
+    layers, oi = planner.parse_cfg(config.yolov3_tiny_cfg_path, 80)
+    plan = planner.build_plan(layers, oi, 1, 416, 416, "bf16")
+    assert plan.ops[0]["kind"] == "conv" and plan.ops[0]["in_f32"] and plan.ops[0]["in_c"] == 3
+    plan = planner.build_plan(layers, oi, 1, 416, 416, "bf16", pad_input=True)
+    assert plan.ops[0]["kind"] == "padin" and plan.ops[1]["in_c"] == 8 and not plan.ops[1]["in_f32"]
+    plan = planner.build_plan(layers, oi, 1, 416, 416, "fp32", pad_input=True)
+    assert plan.ops[1]["in_c"] == 4
+
+
+def test_padded_input_plan_matches_oracle():
+    plan = _check(config.yolov3_tiny_cfg_path, 416, 1, True, pad_input=True)
+    assert plan.ops[0]["kind"] == "padin"

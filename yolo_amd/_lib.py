@@ -30,6 +30,7 @@ class DecodeDesc(ctypes.Structure):
 SIGNATURES = {
     "y3_conv_weight_layout": (c_int, [ctypes.POINTER(ConvDesc)]),
     "y3_conv2d_fused": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_int]),
     "y3_set_conv_tile": (c_int, [c_int]),
     "y3_maxpool2d": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "y3_upsample2x": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
@@ -43,6 +44,7 @@ SIGNATURES = {
     "y3_nms": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "y3_nms_lds_bytes": (c_int, [c_int]),
     "y3_pack_outputs": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_pad_input": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
     "y3_cast_f32_to_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "y3_cast_bf16_to_f32": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "y3_version": (c_int, []),

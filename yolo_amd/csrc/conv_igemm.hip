@@ -607,6 +607,18 @@ int launch_igemm(const ConvArgs &a, int n_pad, hipStream_t stream) {
     return launch_igemm_<BF16, BM, BN, WM, WN, EP_ROWS, true>(a, n_pad, stream);
 }
 
+// Tile choice -> 256 (256x256, 8 waves), 128 (128x128), 64 (128x64), 32 (128x32).  L2/L1 -> LDS bytes per
+// FLOP fall with the tile area, so compute-bound layers (3x3, Cout a multiple of 256, enough rows to
+// fill the chip with 256-row tiles) take the 256x256 tile; everything else the 128-row tiles.
+inline int conv_variant(const y3_conv_desc *d, long M) {
+    const int bn = d->out_c > 64 ? 128 : (d->out_c > 32 ? 64 : 32);
+    if (bn != 128) return bn;
+    int tile = g_conv_tile;
+    if (tile == 0) tile = (d->n_pad % 256 == 0 && d->ksize == 3 && M >= 256 * 256) ? 256 : 128;
+    if (tile == 256 && d->n_pad % 256 != 0) tile = 128;
+    return tile;
+}
+
 inline FastDiv make_fastdiv(int d) {
     unsigned shift = 0;
     while ((1ull << shift) < (unsigned long long)d) ++shift;
@@ -709,7 +721,6 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     if (g_conv_debug & 1) a.H = 0;             // timing experiment: every A tap reads the zero page
     if (g_conv_debug & 8) a.flags |= 1 << 29;  // timing experiment: no A loads at all (garbage results)
     if (g_conv_debug & 16) a.flags |= 1 << 28; // timing experiment: no B loads at all (garbage results)
-    const int bn = bn_for(d->out_c);
     const int bke = bf16 ? 64 : 32;
     a.n_tiles = 0;
     a.step_tap = bke / d->in_c;
@@ -718,30 +729,45 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     a.fd_wo = make_fastdiv(a.Wo);
     a.sub_tap = (bke / 2) / d->in_c;
     a.sub_cin = (bke / 2) % d->in_c;
-    // Tile choice.  L2 -> LDS bytes per FLOP fall with the tile area, so compute-bound layers (3x3,
-    // Cout a multiple of 256) take the 256x256 tile; everything else the 128-row tiles.
-    int tile = g_conv_tile;
-    if (tile == 0) tile = (bn == 128 && d->n_pad % 256 == 0 && d->ksize == 3 && M >= 256 * 256) ? 256 : 128;
-    if (tile == 256 && !(bn == 128 && d->n_pad % 256 == 0)) tile = 128;
-    if (g_conv_debug & 4) {            // ring-pipelined kernels (experiment switch)
-        if (bf16) {
-            if (bn == 128 && tile == 256) return launch_ring<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
-            if (bn == 128) return launch_ring<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
-        } else {
-            if (bn == 128 && tile == 256) return launch_ring<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
-            if (bn == 128) return launch_ring<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
-        }
+    const int v = conv_variant(d, M);
+    const bool ring = g_conv_debug & 4;            // ring-pipelined kernels (experiment switch)
+    if (ring && (v == 256 || v == 128)) {
+        if (bf16) return v == 256 ? launch_ring<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream)
+                                  : launch_ring<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
+        return v == 256 ? launch_ring<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream)
+                        : launch_ring<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
     }
     if (bf16) {
-        if (bn == 128 && tile == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
-        if (bn == 128) return launch_igemm<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
-        if (bn == 64) return launch_igemm<true, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
+        if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+        if (v == 128) return launch_igemm<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
+        if (v == 64) return launch_igemm<true, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
         return launch_igemm<true, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
     }
-    if (bn == 128 && tile == 256) return launch_igemm<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
-    if (bn == 128) return launch_igemm<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
-    if (bn == 64) return launch_igemm<false, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
+    if (v == 256) return launch_igemm<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+    if (v == 128) return launch_igemm<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
+    if (v == 64) return launch_igemm<false, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
     return launch_igemm<false, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
+}
+
+// Which kernel a descriptor runs on, as rocprof will name it (for benches and profiles).
+extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
+    Y3_REQUIRE(d && buf && len > 0, Y3_E_INVALID, "conv_kernel_name: bad arguments");
+    y3_conv_desc chk = *d;
+    const int family = y3_conv_weight_layout(&chk);
+    if (family < 0) return family;
+    const char *t = d->dtype == Y3_BF16 ? "true" : "false";
+    if (family == 1) {
+        snprintf(buf, (size_t)len, "conv_direct_kernel");
+        return Y3_OK;
+    }
+    const long M = (long)d->batch * d->out_h * d->out_w;
+    const int v = conv_variant(d, M);
+    const char *k = (g_conv_debug & 4) && v >= 128 ? "conv_igemm_ring_kernel" : "conv_igemm_kernel";
+    if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
+    else if (v == 128) snprintf(buf, (size_t)len, "%s<%s, 128, 128, 2, 2", k, t);
+    else if (v == 64) snprintf(buf, (size_t)len, "%s<%s, 128, 64, 2, 2", k, t);
+    else snprintf(buf, (size_t)len, "%s<%s, 128, 32, 4, 1", k, t);
+    return Y3_OK;
 }
 
 // Experiment knob (not part of the stable ABI contract): force the conv tile (0 = heuristic).

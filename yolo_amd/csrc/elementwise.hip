@@ -123,6 +123,26 @@ __global__ __launch_bounds__(kThreads) void add_kernel(const u32x4 *a, const u32
     }
 }
 
+// fp32 [pixels][cin] -> T [pixels][16/sizeof(T)] zero-padded: lets the first layer (cin = 3) run on the
+// chunked implicit-GEMM loader.  One 16-byte store per pixel.
+template <bool BF16>
+__global__ __launch_bounds__(kThreads) void pad_input_kernel(const float *in, u32x4 *out, long pixels, int cin) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < pixels; i += (long)gridDim.x * kThreads) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < cin ? in[i * cin + c] : 0.0f;
+        u32x4 o;
+        if constexpr (BF16) {
+            o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
+            o[2] = pack_bf16x2(v[4], v[5]); o[3] = pack_bf16x2(v[6], v[7]);
+        } else {
+            o[0] = __float_as_uint(v[0]); o[1] = __float_as_uint(v[1]);
+            o[2] = __float_as_uint(v[2]); o[3] = __float_as_uint(v[3]);
+        }
+        out[i] = o;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void cast_f32_bf16_kernel(const float *in, unsigned short *out, long n) {
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads)
         out[i] = f32_to_bf16(in[i]);
@@ -204,6 +224,18 @@ extern "C" int y3_shortcut_add(int dtype, const void *a, const void *b, void *ou
         hipLaunchKernelGGL(add_kernel<false>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                            (const u32x4 *)a, (const u32x4 *)b, (u32x4 *)out, (long)pixels, c / epc, a_ld / epc, b_ld / epc, out_ld / epc);
     return y3_check_launch("shortcut_add");
+}
+
+extern "C" int y3_pad_input(int dtype, const float *in, void *out, int64_t pixels, int cin, void *stream) {
+    Y3_REQUIRE(dtype == Y3_F32 || dtype == Y3_BF16, Y3_E_INVALID, "pad_input: dtype %d", dtype);
+    Y3_REQUIRE(in && out && pixels > 0, Y3_E_INVALID, "pad_input: bad arguments");
+    Y3_REQUIRE(cin >= 1 && cin <= (dtype == Y3_BF16 ? 8 : 4), Y3_E_INVALID, "pad_input: %d channels do not fit one 16-byte chunk", cin);
+    Y3_REQUIRE(aligned16(out), Y3_E_ALIGN, "pad_input: output not 16-byte aligned");
+    if (dtype == Y3_BF16)
+        hipLaunchKernelGGL(pad_input_kernel<true>, dim3(grid_for(pixels)), dim3(kThreads), 0, (hipStream_t)stream, in, (u32x4 *)out, (long)pixels, cin);
+    else
+        hipLaunchKernelGGL(pad_input_kernel<false>, dim3(grid_for(pixels)), dim3(kThreads), 0, (hipStream_t)stream, in, (u32x4 *)out, (long)pixels, cin);
+    return y3_check_launch("pad_input");
 }
 
 extern "C" int y3_cast_f32_to_bf16(const float *in, void *out, int64_t n, void *stream) {

@@ -156,7 +156,7 @@ class Plan(object):
         self.conv_layers = []    # layer indices of convs, cfg order
 
 
-def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True):
+def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True, pad_input=False):
     assert dtype in ("bf16", "fp32")
     es = 2 if dtype == "bf16" else 4
     epc = 16 // es
@@ -262,6 +262,11 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
             tens[i] = dict(buf=new_buf(pixels(i) * ld), off=0, ld=ld, c=c)
 
     in_tensor = dict(buf="in", off=0, ld=in_c, c=in_c)
+    # network input with fewer channels than one 16-byte chunk: stage it once, zero padded to a
+    # chunk, so the first conv takes the MFMA path instead of the direct kernel
+    padded_in = None
+    if pad_input and in_c % epc != 0 and in_c < epc:
+        padded_in = dict(buf=new_buf(batch * in_h * in_w * epc), off=0, ld=epc, c=epc)
 
     def tin(j):
         return in_tensor if j < 0 else tens[j]
@@ -270,6 +275,7 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
     plan = Plan()
     plan.batch, plan.dtype, plan.shapes = batch, dtype, shapes
     ops = plan.ops
+    pad_emitted = False
     for i, L in enumerate(layers):
         t = L["type"]
         if t == "conv":
@@ -277,9 +283,15 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
             src = inputs[i][0]
             ih, iw, ic = (in_h, in_w, in_c) if src < 0 else shapes[src]
             oh, ow, oc = shapes[i]
-            op = dict(kind="conv", layer=i, x=tin(src), in_hw=(ih, iw), in_c=ic, out_hw=(oh, ow), out_c=oc,
+            xin, in_f32 = tin(src), src < 0
+            if src < 0 and padded_in is not None:
+                if not pad_emitted:
+                    ops.append(dict(kind="padin", layer=i, x=in_tensor, y=padded_in, pixels=batch * in_h * in_w, c=in_c))
+                    pad_emitted = True
+                xin, in_f32, ic = padded_in, False, epc
+            op = dict(kind="conv", layer=i, x=xin, in_hw=(ih, iw), in_c=ic, out_hw=(oh, ow), out_c=oc,
                       ksize=L["size"], stride=L["stride"], leaky=L["activation"] == "leaky",
-                      in_f32=(src < 0), out_f32=(i in head_of), res=None, ups=False)
+                      in_f32=in_f32, out_f32=(i in head_of), res=None, ups=False)
             tgt = i
             if i in absorbed:
                 tgt = absorbed[i]
