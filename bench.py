@@ -50,8 +50,7 @@ def parse_args():
 
 
 def conv_flops(op, batch):
-    oh, ow = op["out_hw"]
-    return 2.0 * batch * oh * ow * op["out_c"] * op["ksize"] ** 2 * op["in_c"]
+    return planner.op_flops(op, batch)
 
 
 def cpu_baseline(model_cfg, size, n_images, score_threshold):
@@ -160,7 +159,7 @@ def main():
             for tr in traces:
                 for op, e0, e1 in tr:
                     ms = e0.elapsed_time(e1)
-                    if op["kind"] == "conv":
+                    if op["kind"] in ("conv", "stem"):
                         conv_ms += ms
                         k = per_kernel.setdefault(op["kernel"], [0.0, 0.0, 0])
                         k[0] += ms; k[1] += conv_flops(op, nb); k[2] += 1

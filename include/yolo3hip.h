@@ -74,6 +74,24 @@ int y3_conv_weight_layout(y3_conv_desc *desc);
 int y3_conv2d_fused(const y3_conv_desc *desc, const void *in, const void *w, const float *bias,
                     const void *residual, void *out, const void *zeros, void *stream);
 
+/* Fused network stem, bf16 mode: the first three convolutions of Darknet-53 in one launch, the
+ * 32-channel full-resolution tensor between the first two never leaving LDS:
+ *   conv A 3x3 s1 3->c0 on the fp32 NHWC image, conv B 3x3 s2 c0->c1, optional conv C 1x1 c1->c2
+ * (build_model.py:113-179 applied to yolov3.cfg layers 0,1,2), each + bias [+ leaky].
+ * Only c0 = 32, c1 = 64, c2 = 0 or 32.  Weights are in the layouts y3_conv_weight_layout gives
+ * the three layers on their own: w0 fp32 [27][n0_pad] (direct family), w1 bf16 [64][k1_pad],
+ * w2 bf16 [32][k2_pad].  out1 = conv B output (bf16, out1_ld), out2 = conv C output. */
+typedef struct y3_stem_desc {
+    int32_t batch, in_h, in_w;
+    int32_t c0, c1, c2;
+    int32_t n0_pad, k1_pad, k2_pad;
+    int32_t out1_ld, out2_ld;
+    int32_t flags;        /* bit 0/1/2: leaky-ReLU after conv A/B/C */
+} y3_stem_desc;
+int y3_conv_stem(const y3_stem_desc *desc, const float *image, const float *w0, const float *b0,
+                 const void *w1, const float *b1, const void *w2, const float *b2,
+                 void *out1, void *out2, void *stream);
+
 /* Name (prefix) of the kernel a descriptor will run on, as rocprofv3 reports it. Host-only. */
 int y3_conv_kernel_name(const y3_conv_desc *desc, char *buf, int len);
 

@@ -71,6 +71,49 @@ def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=Fals
     return full[..., out_pad[0]:out_pad[0] + O]
 
 
+def run_stem(x, kernels, biases, leaky=(True, True, True), out_pad=(0, 0)):
+    """Fused stem (y3_conv_stem) on an fp32 NHWC image; kernels/biases for conv A, B and optionally C
+    (HWIO).  Returns (out1, out2 or None) as fp32 numpy."""
+    lib = _lib.load()
+    B, H, W, _ = x.shape
+    Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    w0, b0, fam0, _, n0_pad = pack_conv(kernels[0], biases[0], "bf16", True, "cuda")
+    w1, b1, fam1, k1_pad, _ = pack_conv(kernels[1], biases[1], "bf16", False, "cuda")
+    assert fam0 == 1 and fam1 == 0
+    has_c = len(kernels) > 2
+    d = _lib.StemDesc()
+    d.batch, d.in_h, d.in_w = B, H, W
+    d.c0, d.c1, d.c2 = 32, 64, 32 if has_c else 0
+    d.n0_pad, d.k1_pad = n0_pad, k1_pad
+    ld1 = out_pad[0] + 64 + out_pad[1]
+    out1 = torch.full((B, Ho, Wo, ld1), -9.0, dtype=torch.bfloat16, device="cuda")
+    d.out1_ld = ld1
+    w2 = b2 = out2 = None
+    if has_c:
+        w2, b2, fam2, k2_pad, _ = pack_conv(kernels[2], biases[2], "bf16", False, "cuda")
+        assert fam2 == 0
+        d.k2_pad, d.out2_ld = k2_pad, 40
+        out2 = torch.full((B, Ho, Wo, 40), -9.0, dtype=torch.bfloat16, device="cuda")
+    d.flags = sum(1 << j for j, lk in enumerate(leaky) if lk)
+    xin = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    rc = lib.y3_conv_stem(ctypes.byref(d), xin.data_ptr(), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                          w2.data_ptr() if has_c else None, b2.data_ptr() if has_c else None,
+                          out1.data_ptr() + out_pad[0] * 2, out2.data_ptr() if has_c else None, stream())
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    f1 = out1.float().cpu().numpy()
+    if out_pad[0]:
+        assert np.all(f1[..., :out_pad[0]] == -9.0)
+    if out_pad[1]:
+        assert np.all(f1[..., out_pad[0] + 64:] == -9.0)
+    f2 = None
+    if has_c:
+        f2 = out2.float().cpu().numpy()
+        assert np.all(f2[..., 32:] == -9.0)
+        f2 = f2[..., :32]
+    return f1[..., out_pad[0]:out_pad[0] + 64], f2
+
+
 def records_from_dense(boxes, scores, thr):
     """Build the decode kernel's outputs (records, cand_idx, cand_count, class_count) from a
     dense reference-style (boxes [N,4], box_scores [N,C]) pair for ONE image."""

@@ -112,6 +112,55 @@ def test_conv_first_layer_direct(dtype, cout):
     assert np.all(np.abs(got - want) <= tol)
 
 
+@pytest.mark.parametrize("has_c", [True, False])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 48, 80), (1, 37, 45), (3, 16, 32)], ids=str)
+def test_conv_stem_fused(shape, has_c):
+    """Darknet-53 layers 0-2 in one launch (csrc/conv_stem.hip) against the oracle's conv chain with
+    the same bf16 roundings (image, weights, and each layer's stored output)."""
+    B, H, W = shape
+    rng = np.random.default_rng(100 + H + W)
+    x = rng.random((B, H, W, 3), dtype=np.float32)
+    ks = [(rng.standard_normal((3, 3, 3, 32)) * 0.4).astype(np.float32),
+          (rng.standard_normal((3, 3, 32, 64)) * 0.1).astype(np.float32),
+          (rng.standard_normal((1, 1, 64, 32)) * 0.2).astype(np.float32)]
+    bs = [rng.standard_normal(32).astype(np.float32) * 0.2, rng.standard_normal(64).astype(np.float32) * 0.2,
+          rng.standard_normal(32).astype(np.float32) * 0.2]
+    ks = [gpu_util.bf16_round(k) for k in ks]
+    n = 3 if has_c else 2
+    leaky = (True, True, False)
+    got1, got2 = gpu_util.run_stem(x, ks[:n], bs[:n], leaky=leaky, out_pad=(8, 16))
+    a = gpu_util.bf16_round(_ref(gpu_util.bf16_round(x), ks[0], bs[0], 1, leaky[0]))
+    want1 = _ref(a, ks[1], bs[1], 2, leaky[1])
+    assert got1.shape == want1.shape
+    assert np.all(np.abs(got1 - want1) <= 1e-2 * np.maximum(1.0, np.abs(want1)))
+    if has_c:
+        # conv C reads the bf16 tensor the kernel stored
+        want2 = _ref(got1, ks[2], bs[2], 1, leaky[2])
+        assert np.all(np.abs(got2 - want2) <= 1e-2 * np.maximum(1.0, np.abs(want2)))
+    else:
+        assert got2 is None
+
+
+def test_conv_stem_rejects_bad_arguments():
+    import ctypes
+    import torch
+    from yolo_amd import _lib
+    lib = _lib.load()
+    d = _lib.StemDesc()
+    d.batch, d.in_h, d.in_w, d.c0, d.c1, d.c2 = 1, 32, 32, 32, 64, 0
+    d.n0_pad, d.k1_pad, d.out1_ld = 32, 320, 64
+    t = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    p = t.data_ptr()
+    assert lib.y3_conv_stem(ctypes.byref(d), p, p, p, p, p, None, None, p, None, None) == 0
+    d.c0 = 16
+    assert lib.y3_conv_stem(ctypes.byref(d), p, p, p, p, p, None, None, p, None, None) == -1
+    d.c0, d.c2 = 32, 32
+    assert lib.y3_conv_stem(ctypes.byref(d), p, p, p, p, p, None, None, p, None, None) == -1    # conv C without weights
+    d.c2 = 0
+    assert lib.y3_conv_stem(ctypes.byref(d), p, p, p, p, p, None, None, p + 2, None, None) == -2
+    torch.cuda.synchronize()
+
+
 def test_conv_rejects_bad_arguments():
     import ctypes
     import torch
@@ -152,7 +201,7 @@ def test_conv_tile256_equals_tile128(case, dtype):
     outs = {}
     try:
         # low half: tile; high half: experiment bits (4 = ring-pipelined main loop, 2 = no interleave)
-        for tile in (128, 256, (4 << 16) | 128, (4 << 16) | 256, (2 << 16) | 256):
+        for tile in (128, 192, 256, (4 << 16) | 128, (4 << 16) | 256, (2 << 16) | 256):
             _lib.check(lib.y3_set_conv_tile(tile))
             outs[tile] = gpu_util.run_conv(x, k, b, stride, dtype, leaky=leaky, residual=r)
     finally:

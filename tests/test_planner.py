@@ -59,8 +59,31 @@ def test_plan_shapes_and_alignment():
                 if t["buf"][0] == "arena":
                     assert t["buf"][1] % 256 == 0
         # route [-1, 61] and [-1, 36] read one buffer: 768 and 384 channels
-        assert sorted(op["x"]["ld"] for op in plan.ops if op["in_c"] in (768, 384)) == [384, 768]
+        assert sorted(op["x"]["ld"] for op in plan.ops if op.get("in_c") in (768, 384)) == [384, 768]
         assert plan.arena_bytes < 8 * 2 ** 30
+
+
+def test_stem_fusion_plan():
+    """bf16 yolov3 plans run layers 0-2 as one 'stem' launch whose 32-channel full-resolution
+    tensor has no buffer at all; fp32 plans, tiny, and stem=False keep one launch per conv."""
+    layers, oi = planner.parse_cfg(config.yolov3_cfg_path, 80)
+    plan = planner.build_plan(layers, oi, 4, 608, 608, "bf16")
+    kinds = [op["kind"] for op in plan.ops]
+    assert kinds[0] == "stem" and kinds.count("conv") == 72 and len(kinds) == 73
+    st = plan.ops[0]
+    assert st["layers"] == (0, 1, 2) and st["leaky"] == (True, True, True) and st["out_hw"] == (304, 304)
+    assert st["y"]["ld"] == 64 and st["y2"]["ld"] == 32 and st["y"]["buf"] != st["y2"]["buf"]
+    assert plan.conv_layers[:3] == [0, 1, 2] and len(plan.conv_layers) == 75
+    # the shortcut at layer 4 still finds conv B's output as the residual of layer 3's conv
+    assert plan.ops[1]["res"] == st["y"] and plan.ops[1]["x"] == st["y2"]
+    flops = sum(planner.op_flops(op, 1) for op in plan.ops)
+    assert abs(flops / 1e9 - planner.conv_gflops(layers, 608, 608)) < 1e-6
+    unfused = planner.build_plan(layers, oi, 4, 608, 608, "bf16", stem=False)
+    assert [op["kind"] for op in unfused.ops].count("conv") == 75
+    assert plan.arena_bytes <= unfused.arena_bytes
+    assert planner.build_plan(layers, oi, 4, 608, 608, "fp32").ops[0]["kind"] == "conv"
+    tl, toi = planner.parse_cfg(config.yolov3_tiny_cfg_path, 80)
+    assert planner.build_plan(tl, toi, 1, 416, 416, "bf16").ops[0]["kind"] == "conv"
 
 
 def test_layer_walk_quirks():

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from yolo_amd import build_model, config  # noqa: E402
+from yolo_amd import build_model, config, planner  # noqa: E402
 from yolo_amd import darknet_weights as dw  # noqa: E402
 
 
@@ -22,11 +22,12 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--no-stem", action="store_true")
     a = ap.parse_args()
     cfg = config.yolov3_tiny_cfg_path if a.model == "yolov3-tiny" else config.yolov3_cfg_path
     from yolo_amd import _lib
     _lib.check(_lib.load().y3_set_conv_tile(a.tile))
-    net = build_model.Network(cfg, 80, dtype=a.dtype)
+    net = build_model.Network(cfg, 80, dtype=a.dtype, stem=not a.no_stem)
     net.set_params(dw.random_params(net.layers, seed=0))
     x = torch.rand((a.batch, a.size, a.size, 3), device="cuda")
     for _ in range(2):
@@ -47,19 +48,15 @@ def main():
     for i in sorted(acc):
         op, ts = acc[i]
         ms = float(np.median(ts))
+        flops, byt = planner.op_flops(op, nb), planner.op_bytes(op, nb, es)
         if op["kind"] == "conv":
-            oh, ow = op["out_hw"]; ih, iw = op["in_hw"]
-            flops = 2.0 * nb * oh * ow * op["out_c"] * op["ksize"] ** 2 * op["in_c"]
-            ies = 4 if op["in_f32"] else es
-            oes = 4 if op["out_f32"] else es
-            byt = nb * ih * iw * op["in_c"] * ies + nb * oh * ow * op["out_c"] * oes * (4 if op["ups"] else 1)
-            byt += op["out_c"] * op["ksize"] ** 2 * op["in_c"] * es
-            if op["res"] is not None:
-                byt += nb * oh * ow * op["out_c"] * es
+            oh = op["out_hw"][0]
             shape = "%dx%d s%d %d->%d @%d%s%s" % (op["ksize"], op["ksize"], op["stride"], op["in_c"], op["out_c"], oh,
                                                   "+r" if op["res"] is not None else "", "+u" if op["ups"] else "")
+        elif op["kind"] == "stem":
+            shape = "stem 3->" + "->".join(str(c["out_c"]) for c in op["convs"]) + " @%d" % op["out_hw"][0]
         else:
-            flops, byt, shape = 0.0, 0.0, op["kind"]
+            shape = op["kind"]
         ideal = max(flops / peak, byt / 6.3e12) * 1e3
         tot += ms; tot_ideal += ideal
         print("%3d %5d %-22s %9.4f %8.1f %8.0f %8.4f %6.1f%%" % (i, op["layer"], shape, ms, flops / ms / 1e9, byt / ms / 1e6,

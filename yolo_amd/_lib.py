@@ -18,6 +18,11 @@ class ConvDesc(ctypes.Structure):
         "ksize", "stride", "k_pad", "n_pad", "flags")]
 
 
+class StemDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "batch", "in_h", "in_w", "c0", "c1", "c2", "n0_pad", "k1_pad", "k2_pad", "out1_ld", "out2_ld", "flags")]
+
+
 class DecodeDesc(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int32), ("num_scales", ctypes.c_int32), ("num_classes", ctypes.c_int32),
                 ("num_anchors", ctypes.c_int32), ("grid_h", ctypes.c_int32 * 3), ("grid_w", ctypes.c_int32 * 3),
@@ -30,6 +35,7 @@ class DecodeDesc(ctypes.Structure):
 SIGNATURES = {
     "y3_conv_weight_layout": (c_int, [ctypes.POINTER(ConvDesc)]),
     "y3_conv2d_fused": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_conv_stem": (c_int, [ctypes.POINTER(StemDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "y3_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_int]),
     "y3_set_conv_tile": (c_int, [c_int]),
     "y3_maxpool2d": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),

@@ -121,6 +121,34 @@ class _CompiledPlan(object):
             def launch(env, _keep=(d, w, bias)):
                 return fn(dref, x(env), wp, bp, r(env), y(env), zp, env["stream"])
             return launch
+        if kind == "stem":
+            i0, i1, i2 = op["layers"]
+            w0, b0, fam0, _, n0_pad = net._packed[i0]
+            w1, b1, fam1, k1_pad, _ = net._packed[i1]
+            assert fam0 == 1 and fam1 == 0, "stem: unexpected weight layouts"
+            d = _lib.StemDesc()
+            d.batch = B
+            d.in_h, d.in_w = op["in_hw"]
+            d.c0, d.c1, d.c2 = 32, 64, (32 if i2 is not None else 0)
+            d.n0_pad, d.k1_pad, d.out1_ld = n0_pad, k1_pad, op["y"]["ld"]
+            w2 = b2 = None
+            y2 = lambda env: None
+            if i2 is not None:
+                w2, b2, fam2, k2_pad, _ = net._packed[i2]
+                assert fam2 == 0
+                d.k2_pad, d.out2_ld = k2_pad, op["y2"]["ld"]
+                y2 = resolver(op["y2"])
+            d.flags = sum(1 << j for j, lk in enumerate(op["leaky"]) if lk)
+            dref = ctypes.byref(d)
+            op["kernel"] = "conv_stem_kernel"
+            x, y = resolver(op["x"], 4), resolver(op["y"])
+            ptrs = (w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                    w2.data_ptr() if w2 is not None else None, b2.data_ptr() if b2 is not None else None)
+            fn = lib.y3_conv_stem
+
+            def launch(env, _keep=(d, w0, b0, w1, b1, w2, b2)):
+                return fn(dref, x(env), ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], y(env), y2(env), env["stream"])
+            return launch
         if kind == "padin":
             x, y = resolver(op["x"], 4), resolver(op["y"])
             args = (op["pixels"], op["c"])
@@ -149,7 +177,7 @@ class _CompiledPlan(object):
 class Network(object):
     """The compiled detector: cfg layers + packed device weights + cached launch plans."""
 
-    def __init__(self, config_path, num_classes, dtype=None, device=None, fuse=True, pad_input=False):
+    def __init__(self, config_path, num_classes, dtype=None, device=None, fuse=True, pad_input=False, stem=True):
         self.config_path = config_path
         self.num_classes = num_classes
         self.dtype = dtype or config.compute_dtype
@@ -159,6 +187,7 @@ class Network(object):
         # pad_input: stage the 3-channel image zero-padded to one 16-byte chunk so the first conv runs on
         # the MFMA kernel.  Measured slower than the direct kernel at 608 (1.05 vs 0.87 ms), so off by default.
         self.pad_input = pad_input
+        self.stem = stem            # fuse Darknet-53's first three convolutions into one launch (bf16 mode)
         self.layers, self.out_index = planner.parse_cfg(config_path, num_classes, config.num_anchors_per_scale)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.params = None
@@ -200,7 +229,7 @@ class Network(object):
             if self._packed is None:
                 raise RuntimeError("weights are not loaded: call load_weights(net, path) first")
             plan = planner.build_plan(self.layers, self.out_index, batch, height, width, self.dtype, fuse=self.fuse,
-                                      pad_input=self.pad_input)
+                                      pad_input=self.pad_input, stem=self.stem)
             cp = _CompiledPlan(self, plan)
             self._plans[key] = cp
         return cp

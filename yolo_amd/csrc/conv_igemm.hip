@@ -607,15 +607,28 @@ int launch_igemm(const ConvArgs &a, int n_pad, hipStream_t stream) {
     return launch_igemm_<BF16, BM, BN, WM, WN, EP_ROWS, true>(a, n_pad, stream);
 }
 
-// Tile choice -> 256 (256x256, 8 waves), 128 (128x128), 64 (128x64), 32 (128x32).  L2/L1 -> LDS bytes per
-// FLOP fall with the tile area, so compute-bound layers (3x3, Cout a multiple of 256, enough rows to
-// fill the chip with 256-row tiles) take the 256x256 tile; everything else the 128-row tiles.
+// Tile choice -> 256 (256x256, 8 waves), 192 (192x256), 128 (128x128, 2 workgroups per CU), 64 (128x64),
+// 32 (128x32).  L2 -> LDS bytes per FLOP fall with the tile area, so the big tiles win whenever they fill
+// the chip; what decides between them is wave quantisation: rounds = ceil(tiles / resident workgroups),
+// priced by the measured relative cost of one tile (profiles/r01_layer_report_v3_*: a 192x256 tile costs
+// 0.80 of a 256x256 one, a 128x128 one 0.55 with two of them resident per CU).
 inline int conv_variant(const y3_conv_desc *d, long M) {
     const int bn = d->out_c > 64 ? 128 : (d->out_c > 32 ? 64 : 32);
     if (bn != 128) return bn;
     int tile = g_conv_tile;
-    if (tile == 0) tile = (d->n_pad % 256 == 0 && d->ksize == 3 && M >= 256 * 256) ? 256 : 128;
-    if (tile == 256 && d->n_pad % 256 != 0) tile = 128;
+    if (tile == 0) {
+        tile = 128;
+        if (d->n_pad % 256 == 0) {
+            const long cus = 256;
+            auto rounds = [&](long bm, long bnn, long per_cu) {
+                const long tiles = ((M + bm - 1) / bm) * (d->n_pad / bnn);
+                return (tiles + cus * per_cu - 1) / (cus * per_cu);
+            };
+            const long c256 = rounds(256, 256, 1) * 256, c192 = rounds(192, 256, 1) * 205, c128 = rounds(128, 128, 2) * 142;
+            tile = (c256 <= c192 && c256 <= c128) ? 256 : (c192 <= c128 ? 192 : 128);
+        }
+    }
+    if (tile >= 192 && d->n_pad % 256 != 0) tile = 128;
     return tile;
 }
 
@@ -729,8 +742,9 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     a.fd_wo = make_fastdiv(a.Wo);
     a.sub_tap = (bke / 2) / d->in_c;
     a.sub_cin = (bke / 2) % d->in_c;
-    const int v = conv_variant(d, M);
+    int v = conv_variant(d, M);
     const bool ring = g_conv_debug & 4;            // ring-pipelined kernels (experiment switch)
+    if (ring && v == 192) v = 256;
     if (ring && (v == 256 || v == 128)) {
         if (bf16) return v == 256 ? launch_ring<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream)
                                   : launch_ring<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
@@ -739,11 +753,13 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     }
     if (bf16) {
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+        if (v == 192) return launch_igemm<true, 192, 256, 2, 4, 96>(a, d->n_pad, stream);
         if (v == 128) return launch_igemm<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
         if (v == 64) return launch_igemm<true, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
         return launch_igemm<true, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
     }
     if (v == 256) return launch_igemm<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+    if (v == 192) return launch_igemm<false, 192, 256, 2, 4, 96>(a, d->n_pad, stream);
     if (v == 128) return launch_igemm<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
     if (v == 64) return launch_igemm<false, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
     return launch_igemm<false, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
@@ -764,6 +780,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     const int v = conv_variant(d, M);
     const char *k = (g_conv_debug & 4) && v >= 128 ? "conv_igemm_ring_kernel" : "conv_igemm_kernel";
     if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
+    else if (v == 192) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
     else if (v == 128) snprintf(buf, (size_t)len, "%s<%s, 128, 128, 2, 2", k, t);
     else if (v == 64) snprintf(buf, (size_t)len, "%s<%s, 128, 64, 2, 2", k, t);
     else snprintf(buf, (size_t)len, "%s<%s, 128, 32, 4, 1", k, t);
@@ -774,7 +791,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
-    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 256, Y3_E_INVALID, "conv tile %d (0, 128 or 256)", tile);
+    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256, Y3_E_INVALID, "conv tile %d (0, 128, 192 or 256)", tile);
     g_conv_tile = tile;
     return Y3_OK;
 }

@@ -156,7 +156,30 @@ class Plan(object):
         self.conv_layers = []    # layer indices of convs, cfg order
 
 
-def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True, pad_input=False):
+def find_stem(layers, inputs, uses, head_of, in_c=3):
+    """Darknet-53's first layers as one launch (csrc/conv_stem.hip): conv 3x3 s1 3->32, conv 3x3 s2
+    32->64 and, if it follows, conv 1x1 64->32.  Returns (i0, i1, i2 or None) or None."""
+    convs = [i for i, L in enumerate(layers) if L["type"] == "conv"]
+    if len(convs) < 2:
+        return None
+    i0, i1 = convs[0], convs[1]
+    A, B = layers[i0], layers[i1]
+    if not (inputs[i0] == [-1] and in_c == 3 and (A["size"], A["stride"], A["filters"]) == (3, 1, 32)):
+        return None
+    if not (inputs[i1] == [i0] and uses[i0] == 1 and (B["size"], B["stride"], B["filters"]) == (3, 2, 64)):
+        return None
+    if i0 in head_of or i1 in head_of:
+        return None
+    i2 = None
+    if len(convs) > 2:
+        c = convs[2]
+        C = layers[c]
+        if inputs[c] == [i1] and (C["size"], C["stride"], C["filters"]) == (1, 1, 32) and c not in head_of:
+            i2 = c
+    return (i0, i1, i2)
+
+
+def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True, pad_input=False, stem=True):
     assert dtype in ("bf16", "fp32")
     es = 2 if dtype == "bf16" else 4
     epc = 16 // es
@@ -193,12 +216,15 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
     # ---- fusion decisions -------------------------------------------------------------------
     fused_into = {}      # consumer layer (shortcut/upsample) -> producing conv
     absorbed = {}        # conv -> consumer layer whose tensor it writes
+    stem_layers = find_stem(layers, inputs, uses, head_of, in_c) if (fuse and stem and dtype == "bf16" and not pad_input) else None
     if fuse:
         for i, L in enumerate(layers):
             if L["type"] not in ("shortcut", "upsample") or i == 0:
                 continue
             p = inputs[i][-1]
             if p < 0 or layers[p]["type"] != "conv" or uses[p] != 1 or p in head_of or p in absorbed:
+                continue
+            if stem_layers is not None and p in stem_layers:
                 continue
             if layers[p]["cin"] % epc != 0:        # direct-conv family has no fused epilogue
                 continue
@@ -239,7 +265,7 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
 
     for i, L in enumerate(layers):
         t = L["type"]
-        if t == "yolo" or i in absorbed:
+        if t == "yolo" or i in absorbed or (stem_layers is not None and i == stem_layers[0]):
             continue
         c = shapes[i][2]
         if t == "route":
@@ -278,7 +304,16 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
     pad_emitted = False
     for i, L in enumerate(layers):
         t = L["type"]
-        if t == "conv":
+        if t == "conv" and stem_layers is not None and i in stem_layers:
+            plan.conv_layers.append(i)
+            if i == stem_layers[0]:
+                i0, i1, i2 = stem_layers
+                ops.append(dict(kind="stem", layer=i0, layers=stem_layers, x=in_tensor, in_hw=(in_h, in_w),
+                                out_hw=shapes[i1][:2], y=tens[i1], y2=tens[i2] if i2 is not None else None,
+                                leaky=tuple(layers[j]["activation"] == "leaky" for j in stem_layers if j is not None),
+                                convs=[dict(out_hw=shapes[j][:2], out_c=shapes[j][2], ksize=layers[j]["size"], in_c=layers[j]["cin"])
+                                       for j in stem_layers if j is not None]))
+        elif t == "conv":
             plan.conv_layers.append(i)
             src = inputs[i][0]
             ih, iw, ic = (in_h, in_w, in_c) if src < 0 else shapes[src]
@@ -330,7 +365,7 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
 
     birth, death = {}, {}
     for k, op in enumerate(ops):
-        for b in refs(op, ("y",)):
+        for b in refs(op, ("y", "y2")):
             birth.setdefault(b, k)
             death[b] = max(death.get(b, k), k)
         for b in refs(op, ("x", "a", "b", "res")):
@@ -369,10 +404,39 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
         return dict(buf=where, off=tn["off"], ld=tn["ld"], c=tn["c"])
 
     for op in ops:
-        for k in ("x", "y", "a", "b", "res"):
+        for k in ("x", "y", "y2", "a", "b", "res"):
             if k in op:
                 op[k] = resolve(op[k])
     return plan
+
+
+def op_flops(op, batch):
+    """Algorithmic FLOPs (2*MACs) of one conv / stem launch."""
+    if op["kind"] == "conv":
+        oh, ow = op["out_hw"]
+        return 2.0 * batch * oh * ow * op["out_c"] * op["ksize"] ** 2 * op["in_c"]
+    if op["kind"] == "stem":
+        return sum(2.0 * batch * c["out_hw"][0] * c["out_hw"][1] * c["out_c"] * c["ksize"] ** 2 * c["in_c"] for c in op["convs"])
+    return 0.0
+
+
+def op_bytes(op, batch, es):
+    """Algorithmic HBM bytes of one conv / stem launch: input + output(s) (+ residual) + weights."""
+    if op["kind"] == "conv":
+        oh, ow = op["out_hw"]; ih, iw = op["in_hw"]
+        byt = batch * ih * iw * op["in_c"] * (4 if op["in_f32"] else es)
+        byt += batch * oh * ow * op["out_c"] * (4 if op["out_f32"] else es) * (4 if op["ups"] else 1)
+        byt += op["out_c"] * op["ksize"] ** 2 * op["in_c"] * es
+        if op["res"] is not None:
+            byt += batch * oh * ow * op["out_c"] * es
+        return float(byt)
+    if op["kind"] == "stem":
+        ih, iw = op["in_hw"]; oh, ow = op["out_hw"]
+        byt = batch * ih * iw * 3 * 4
+        for c in op["convs"][1:]:
+            byt += batch * oh * ow * c["out_c"] * es
+        return float(byt)
+    return 0.0
 
 
 def conv_gflops(layers, in_h, in_w):
