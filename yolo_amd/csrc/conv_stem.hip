@@ -28,11 +28,13 @@ constexpr int IM_H = AP_H + 2;                 // 19 image rows
 constexpr int IM_W3 = (AP_W + 2) * 3;          // 105 floats per image-patch row
 constexpr int IM_PITCH = 106;
 constexpr int IM_ELEMS = IM_H * IM_W3;         // 1995
-constexpr int IMG_LOADS = (IM_ELEMS + 255) / 256;
+constexpr int IMG_ROWS_PER_WAVE = (IM_H + 3) / 4;   // 5: wave w stages image-patch rows w, w+4, ...; two 64-lane halves per row
 constexpr int NPIX_A = AP_H * AP_W;            // 561
 constexpr int NBLK_A = (NPIX_A + 15) / 16;     // 36
 constexpr int P_BYTES = 3 * AP_H * TW * 64;    // 52 224
 constexpr int IMG_BYTES = (IM_H * IM_PITCH * 2 + 15) / 16 * 16;
+constexpr int BIAS_BYTES = (32 + 64 + 32) * 4;   // b0 | b1 | b2
+constexpr int WC_BYTES = 32 * 64 * 2;          // conv C weights [32][64] bf16
 
 struct StemArgs {
     const float *img;            // [B][H][W][3]
@@ -45,7 +47,7 @@ struct StemArgs {
     int B, H, W, Ho, Wo, tiles_y, tiles_x, n0_pad, k1_pad, k2_pad, out1_ld, out2_ld, flags;
 };
 
-__device__ __forceinline__ f32x4 bias_act(f32x4 v, const float *bias, bool leaky) {
+__device__ __forceinline__ f32x4 bias_act(f32x4 v, const float *bias, bool leaky) {     // bias: LDS
     v += *(const f32x4 *)bias;
     if (leaky) {
 #pragma unroll
@@ -69,9 +71,11 @@ __device__ __forceinline__ u32x4 pair_lanes(f32x4 x, f32x4 y) {
 
 template <bool HAS_C>
 __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[P_BYTES + IMG_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[P_BYTES + IMG_BYTES + BIAS_BYTES + WC_BYTES];
     char *P = smem;
     unsigned short *img = (unsigned short *)(smem + P_BYTES);
+    float *bias_s = (float *)(smem + P_BYTES + IMG_BYTES);     // b0[32] | b1[64] | b2[32]
+    char *wc_s = smem + P_BYTES + IMG_BYTES + BIAS_BYTES;       // conv C weights, row pitch 128 B, chunk c of row n at slot c ^ (n & 7)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -80,18 +84,25 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
     const bool leaky_a = p.flags & 1, leaky_b = p.flags & 2, leaky_c = p.flags & 4;
 
     // ---- weights that stay in registers ------------------------------------------------------
+    // conv A k-slots: lane group fq < 3 holds image row kh = fq, (kw, c) = 0..7; group 3 holds the ninth
+    // (kw, c) = (2, 2) of rows 0..2 and five zeros.  So a lane's 8 values are img[k_a + i * k_s], i < k_n.
     bf16x8 wa[2];
-    int koff[8];                    // image-patch offset of this lane's k = fq*8 + i, -1 beyond k = 26
+    const int k_a = fq < 3 ? fq * IM_PITCH : 8, k_s = fq < 3 ? 1 : IM_PITCH, k_n = fq < 3 ? 8 : 3;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int k = fq * 8 + i;
-        const int kh = k / 9;
-        koff[i] = k < 27 ? kh * IM_PITCH + (k - kh * 9) : -1;
+        const int k = fq < 3 ? fq * 9 + i : i * 9 + 8;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-            const float v = k < 27 ? p.w0[k * p.n0_pad + nb * 16 + frow] : 0.0f;
+            const float v = i < k_n ? p.w0[k * p.n0_pad + nb * 16 + frow] : 0.0f;
             wa[nb][i] = (short)f32_to_bf16(v);
         }
+    }
+    if (tid < 32) bias_s[tid] = p.b0[tid];
+    if (tid < 64) bias_s[32 + tid] = p.b1[tid];
+    if constexpr (HAS_C) {
+        if (tid < 32) bias_s[96 + tid] = p.b2[tid];
+        const int n = tid >> 3, c = tid & 7;                       // 32 rows x 8 chunks = 256 threads
+        *(u32x4 *)(wc_s + n * 128 + ((c ^ (n & 7)) * 16)) = *(const u32x4 *)(p.w2 + ((long)n * p.k2_pad + c * 8) * 2);
     }
     bf16x8 wb[9][4];
 #pragma unroll
@@ -100,28 +111,40 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         for (int nb = 0; nb < 4; ++nb)
             wb[tap][nb] = *(const bf16x8 *)(p.w1 + ((long)(nb * 16 + frow) * p.k1_pad + tap * 32 + fq * 8) * 2);
     const int perm = ((fq & 1) << 1) | (fq >> 1);              // conv C: k-slot fq holds channels perm*8.. (see pair_lanes)
-    const char *wc_lane = HAS_C ? p.w2 + ((long)frow * p.k2_pad + perm * 8) * 2 : nullptr;
 
     const int tiles_img = p.tiles_y * p.tiles_x;
     const int total = p.B * tiles_img;
     const long row3 = (long)p.W * 3;
 
-    float pre[IMG_LOADS];
+    // Patch rows are dealt to waves (row = wave + 4*q) so that the row's address and its inside-the-image
+    // test are wave-uniform; lanes take columns lane and lane + 64 of the row's 105 floats.
+    float pre[IMG_ROWS_PER_WAVE][2];
+    unsigned pre_ok = 0;            // which of pre[] lie inside the image (applied when the patch is staged, so that
+                                    // nothing consumes the loads, and waits for them, before the next tile)
     auto load_patch = [&](int t) {
         const int b = t / tiles_img;
         const int r = t - b * tiles_img;
         const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
         const int y0 = 2 * ty * TH - 2, x0 = (2 * tx * TW - 2) * 3;
+        const int ix0 = x0 + lane, ix1 = x0 + lane + 64;
+        const bool okx0 = (unsigned)ix0 < (unsigned)row3, okx1 = lane + 64 < IM_W3 && (unsigned)ix1 < (unsigned)row3;
+        const int cx0 = min(max(ix0, 0), (int)row3 - 1), cx1 = min(max(ix1, 0), (int)row3 - 1);
+        pre_ok = 0;
 #pragma unroll
-        for (int q = 0; q < IMG_LOADS; ++q) {
-            const int i = tid + 256 * q;
-            const int rr = i / IM_W3, cc = i - rr * IM_W3;
-            const int iy = y0 + rr, ix = x0 + cc;
-            const bool ok = i < IM_ELEMS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)row3;
-            pre[q] = ok ? p.img[((long)b * p.H + iy) * row3 + ix] : 0.0f;
+        for (int q = 0; q < IMG_ROWS_PER_WAVE; ++q) {
+            const int iy = y0 + wave + 4 * q;
+            const bool oky = wave + 4 * q < IM_H && (unsigned)iy < (unsigned)p.H;
+            const float *rowp = p.img + ((long)b * p.H + min(max(iy, 0), p.H - 1)) * row3;     // always load (clamped), select later
+            pre[q][0] = rowp[cx0];
+            pre[q][1] = rowp[cx1];
+            pre_ok |= ((oky && okx0) ? 1u : 0u) << (2 * q) | ((oky && okx1) ? 2u : 0u) << (2 * q);
         }
     };
 
+    // All weight loads retire here, and the compiler's wait-count model knows it (a builtin, not inline asm):
+    // otherwise it assumes they may still be pending at the loop header and drains vmcnt, prefetch included,
+    // before the first use of the weights in every iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     int t = blockIdx.x;
     if (t < total) load_patch(t);
     for (; t < total; t += gridDim.x) {
@@ -132,10 +155,13 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
 
         // ---- 1. image patch -> LDS (bf16) ---------------------------------------------------
 #pragma unroll
-        for (int q = 0; q < IMG_LOADS; ++q) {
-            const int i = tid + 256 * q;
-            const int rr = i / IM_W3, cc = i - rr * IM_W3;
-            if (i < IM_ELEMS) img[rr * IM_PITCH + cc] = f32_to_bf16(pre[q]);
+        for (int q = 0; q < IMG_ROWS_PER_WAVE; ++q) {
+            const int rr = wave + 4 * q;
+            if (rr < IM_H) {
+                img[rr * IM_PITCH + lane] = ((pre_ok >> (2 * q)) & 1u) ? f32_to_bf16(pre[q][0]) : (unsigned short)0;
+                if (lane + 64 < IM_W3)
+                    img[rr * IM_PITCH + lane + 64] = ((pre_ok >> (2 * q + 1)) & 1u) ? f32_to_bf16(pre[q][1]) : (unsigned short)0;
+            }
         }
         __syncthreads();            // patch visible; every wave is past step 3 of the previous tile
         if (t + (int)gridDim.x < total) load_patch(t + gridDim.x);
@@ -149,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
             const int base = py * IM_PITCH + px * 3;
             bf16x8 xf;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xf[i] = koff[i] >= 0 ? (short)img[base + koff[i]] : (short)0;
+            for (int i = 0; i < 8; ++i) xf[i] = i < k_n ? (short)img[base + k_a + i * k_s] : (short)0;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             f32x4 a[2];
             a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], xf, z, 0, 0, 0);
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
             const int sw0 = ((oxe >> 3) & 1) << 1, sw2 = (((oxe - 1) >> 3) & 1) << 1;
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                f32x4 v = bias_act(a[nb], p.b0 + nb * 16 + fq * 4, leaky_a);
+                f32x4 v = bias_act(a[nb], bias_s + nb * 16 + fq * 4, leaky_a);
                 uint2 o;
                 o.x = inimg ? pack_bf16x2(v[0], v[1]) : 0u;
                 o.y = inimg ? pack_bf16x2(v[2], v[3]) : 0u;
@@ -178,59 +204,50 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         __syncthreads();
 
         // ---- 3. conv B: 9 taps, two output rows per wave ---------------------------------------
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // one output row at a time (four independent accumulator chains are enough to pace the MFMA pipe,
+        // and the second row's accumulators would not fit next to the 144 weight registers)
         const int slot = (fq ^ (((frow >> 3) & 1) << 1)) * 16;
+        const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;       // first of this lane's 8 channels in a pair
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int mb = 0; mb < 2; ++mb) {
+            f32x4 acc[4];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
+            for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
                     const int row = 2 * (2 * wave + mb) + kh;
                     const bf16x8 xf = *(const bf16x8 *)(P + ((kw * AP_H + row) * TW + frow) * 64 + slot);
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kh * 3 + kw][nb], xf, acc[mb][nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kh * 3 + kw][nb], xf, acc[nb], 0, 0, 0);
                 }
-            }
 
-        // ---- epilogue B (+ conv C) ------------------------------------------------------------
-        const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;       // first of this lane's 8 channels in a pair
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+            // ---- epilogue B (+ conv C) --------------------------------------------------------
             const int oy = oy0 + 2 * wave + mb, ox = ox0 + frow;
             const bool ok = oy < p.Ho && ox < p.Wo;
             const long pix = ((long)b * p.Ho + oy) * p.Wo + ox;
             u32x4 y[2];
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                const f32x4 vx = bias_act(acc[mb][2 * pr], p.b1 + (2 * pr) * 16 + fq * 4, leaky_b);
-                const f32x4 vy = bias_act(acc[mb][2 * pr + 1], p.b1 + (2 * pr + 1) * 16 + fq * 4, leaky_b);
+                const f32x4 vx = bias_act(acc[2 * pr], bias_s + 32 + (2 * pr) * 16 + fq * 4, leaky_b);
+                const f32x4 vy = bias_act(acc[2 * pr + 1], bias_s + 32 + (2 * pr + 1) * 16 + fq * 4, leaky_b);
                 y[pr] = pair_lanes(vx, vy);
                 if (ok) *(u32x4 *)(p.out1 + (pix * p.out1_ld + pr * 32 + cb) * 2) = y[pr];
             }
             if constexpr (HAS_C) {
-                // conv C's 4 KB of weights are re-read per tile (L1-resident) rather than held in registers
-                bf16x8 wc[2][2];
+                f32x4 c2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        wc[kb][nb] = *(const bf16x8 *)(wc_lane + ((long)nb * 16 * p.k2_pad + kb * 32) * 2);
-                f32x4 c2[2];
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    c2[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-                        c2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[kb][nb], __builtin_bit_cast(bf16x8, y[kb]), c2[nb], 0, 0, 0);
-                }
-                const f32x4 vx = bias_act(c2[0], p.b2 + fq * 4, leaky_c);
-                const f32x4 vy = bias_act(c2[1], p.b2 + 16 + fq * 4, leaky_c);
+                    for (int nb = 0; nb < 2; ++nb) {               // conv C's weights come from LDS, per use
+                        const int n = nb * 16 + frow, c = kb * 4 + perm;
+                        const bf16x8 wc = *(const bf16x8 *)(wc_s + n * 128 + ((c ^ (n & 7)) * 16));
+                        c2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc, __builtin_bit_cast(bf16x8, y[kb]), c2[nb], 0, 0, 0);
+                    }
+                const f32x4 vx = bias_act(c2[0], bias_s + 96 + fq * 4, leaky_c);
+                const f32x4 vy = bias_act(c2[1], bias_s + 96 + 16 + fq * 4, leaky_c);
                 const u32x4 o = pair_lanes(vx, vy);
                 if (ok) *(u32x4 *)(p.out2 + (pix * p.out2_ld + cb) * 2) = o;
             }
