@@ -25,16 +25,17 @@ constexpr int TH = 8, TW = 16;                 // tile of conv-B output pixels
 constexpr int AP_H = 2 * TH + 1;               // 17 rows of conv-A output under the tile
 constexpr int AP_W = 2 * TW + 1;               // 33 columns
 constexpr int IM_H = AP_H + 2;                 // 19 image rows
-constexpr int IM_W3 = (AP_W + 2) * 3;          // 105 floats per image-patch row
-constexpr int IM_PITCH = 106;
-constexpr int IM_ELEMS = IM_H * IM_W3;         // 1995
-constexpr int IMG_ROWS_PER_WAVE = (IM_H + 3) / 4;   // 5: wave w stages image-patch rows w, w+4, ...; two 64-lane halves per row
-constexpr int NPIX_A = AP_H * AP_W;            // 561
-constexpr int NBLK_A = (NPIX_A + 15) / 16;     // 36
+constexpr int IM_W = AP_W + 2;                 // 35 image columns
+constexpr int IM_PITCH = 36;                   // LDS patch row pitch in pixels; a pixel is 4 bf16 (r, g, b, 0) = 8 bytes
+constexpr int IM_PIX = IM_H * IM_W;            // 665
+constexpr int IMG_LOADS = (IM_PIX + 255) / 256;   // 3 pixels per thread
 constexpr int P_BYTES = 3 * AP_H * TW * 64;    // 52 224
-constexpr int IMG_BYTES = (IM_H * IM_PITCH * 2 + 15) / 16 * 16;
+constexpr int IMG_BYTES = IM_H * IM_PITCH * 8;  // 5 472
 constexpr int BIAS_BYTES = (32 + 64 + 32) * 4;   // b0 | b1 | b2
 constexpr int WC_BYTES = 32 * 64 * 2;          // conv C weights [32][64] bf16
+constexpr int WA_BYTES = 4 * 64 * 16;          // conv A weight fragments [k-block][n-block][lane]
+constexpr int WB8_BYTES = 4 * 64 * 16;         // conv B weight fragments of the ninth tap [n-block][lane]
+constexpr int DUMP_BYTES = 64 * 8;             // target of stores that have no destination
 
 struct StemArgs {
     const float *img;            // [B][H][W][3]
@@ -45,14 +46,15 @@ struct StemArgs {
     const float *b2;
     char *out1, *out2;
     int B, H, W, Ho, Wo, tiles_y, tiles_x, n0_pad, k1_pad, k2_pad, out1_ld, out2_ld, flags;
+    unsigned out1_bytes, out2_bytes;
 };
 
-__device__ __forceinline__ f32x4 bias_act(f32x4 v, const float *bias, bool leaky) {     // bias: LDS
-    v += *(const f32x4 *)bias;
-    if (leaky) {
+// leaky-ReLU as max(x, slope*x) (slope 0.1, or 1 for a linear layer): a median with +inf, branch-free.
+// Bit-identical to x > 0 ? x : 0.1x for every non-NaN x.  The bias is not added here: it is the initial
+// value of the MFMA accumulator (one LDS read instead of an LDS read and four adds).
+__device__ __forceinline__ f32x4 act(f32x4 v, float slope) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = leaky01(v[j]);
-    }
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], slope * v[j], __builtin_inff());
     return v;
 }
 
@@ -71,9 +73,9 @@ __device__ __forceinline__ u32x4 pair_lanes(f32x4 x, f32x4 y) {
 
 template <bool HAS_C>
 __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[P_BYTES + IMG_BYTES + BIAS_BYTES + WC_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[P_BYTES + IMG_BYTES + BIAS_BYTES + WC_BYTES + WA_BYTES + WB8_BYTES + DUMP_BYTES];
     char *P = smem;
-    unsigned short *img = (unsigned short *)(smem + P_BYTES);
+    char *img = smem + P_BYTES;                                 // [IM_H][IM_PITCH] pixels of 4 bf16
     float *bias_s = (float *)(smem + P_BYTES + IMG_BYTES);     // b0[32] | b1[64] | b2[32]
     char *wc_s = smem + P_BYTES + IMG_BYTES + BIAS_BYTES;       // conv C weights, row pitch 128 B, chunk c of row n at slot c ^ (n & 7)
 
@@ -81,22 +83,32 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
-    const bool leaky_a = p.flags & 1, leaky_b = p.flags & 2, leaky_c = p.flags & 4;
+    char *wa_s = smem + P_BYTES + IMG_BYTES + BIAS_BYTES + WC_BYTES + lane * 16;   // this lane's conv A fragments, 1 KiB apart
+    const float slope_a = (p.flags & 1) ? 0.1f : 1.0f, slope_b = (p.flags & 2) ? 0.1f : 1.0f, slope_c = (p.flags & 4) ? 0.1f : 1.0f;
 
     // ---- weights that stay in registers ------------------------------------------------------
-    // conv A k-slots: lane group fq < 3 holds image row kh = fq, (kw, c) = 0..7; group 3 holds the ninth
-    // (kw, c) = (2, 2) of rows 0..2 and five zeros.  So a lane's 8 values are img[k_a + i * k_s], i < k_n.
-    bf16x8 wa[2];
-    const int k_a = fq < 3 ? fq * IM_PITCH : 8, k_s = fq < 3 ? 1 : IM_PITCH, k_n = fq < 3 ? 8 : 3;
+    // conv A as two MFMA k-blocks over 8-byte (r,g,b,0) pixels: lane group fq < 3 holds image row kh = fq;
+    // k-block 0 = pixels px, px+1 (kw 0, 1), k-block 1 = pixels px+2, px+3 (kw 2, and a pixel whose weights are
+    // zero); the fourth channel and all of lane group 3 have zero weights too.  Every fragment read is then an
+    // aligned ds_read_b64 at a compile-time offset from one per-lane address: no gather arithmetic.
+    // The four weight fragments live in LDS (every wave writes the same values) and are re-read per block.
+    if (wave == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = fq < 3 ? fq * 9 + i : i * 9 + 8;
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const float v = i < k_n ? p.w0[k * p.n0_pad + nb * 16 + frow] : 0.0f;
-            wa[nb][i] = (short)f32_to_bf16(v);
-        }
+            for (int nb = 0; nb < 2; ++nb) {
+                bf16x8 w;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kw = kb * 2 + (i >> 2), c = i & 3;
+                    const bool used = fq < 3 && kw < 3 && c < 3;
+                    const float v = used ? p.w0[(fq * 9 + kw * 3 + c) * p.n0_pad + nb * 16 + frow] : 0.0f;
+                    w[i] = (short)f32_to_bf16(v);
+                }
+                *(bf16x8 *)(wa_s + (kb * 2 + nb) * 1024) = w;
+            }
     }
+    if (tid < IM_H) *(uint2 *)(img + (tid * IM_PITCH + IM_W) * 8) = uint2{0u, 0u};      // the pad column stays zero
     if (tid < 32) bias_s[tid] = p.b0[tid];
     if (tid < 64) bias_s[32 + tid] = p.b1[tid];
     if constexpr (HAS_C) {
@@ -104,101 +116,148 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         const int n = tid >> 3, c = tid & 7;                       // 32 rows x 8 chunks = 256 threads
         *(u32x4 *)(wc_s + n * 128 + ((c ^ (n & 7)) * 16)) = *(const u32x4 *)(p.w2 + ((long)n * p.k2_pad + c * 8) * 2);
     }
-    bf16x8 wb[9][4];
+    // conv B: taps 0..7 stay in registers (128 of them); the ninth tap's fragments would not fit beside the
+    // rest of the kernel, they sit in LDS next to conv A's (wa_s + 4 KiB) and are re-read per output row.
+    bf16x8 wb[8][4];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < 8; ++tap)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
             wb[tap][nb] = *(const bf16x8 *)(p.w1 + ((long)(nb * 16 + frow) * p.k1_pad + tap * 32 + fq * 8) * 2);
+    if (wave == 0) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+            *(bf16x8 *)(wa_s + WA_BYTES + nb * 1024) = *(const bf16x8 *)(p.w1 + ((long)(nb * 16 + frow) * p.k1_pad + 8 * 32 + fq * 8) * 2);
+    }
     const int perm = ((fq & 1) << 1) | (fq >> 1);              // conv C: k-slot fq holds channels perm*8.. (see pair_lanes)
 
     const int tiles_img = p.tiles_y * p.tiles_x;
     const int total = p.B * tiles_img;
-    const long row3 = (long)p.W * 3;
+    // Outputs go through buffer descriptors: a lane with nothing to store gets an out-of-range offset and the
+    // hardware drops its store.  No branch around the stores means their number per tile is fixed, which lets
+    // the compiler wait for the prefetched image loads with an exact vmcnt instead of draining the stores too.
+    const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void *)p.out1, 0, p.out1_bytes, 0x00020000);
+    const auto rsrc2 = __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_C ? p.out2 : p.out1), 0, HAS_C ? p.out2_bytes : 0u, 0x00020000);
 
-    // Patch rows are dealt to waves (row = wave + 4*q) so that the row's address and its inside-the-image
-    // test are wave-uniform; lanes take columns lane and lane + 64 of the row's 105 floats.
-    float pre[IMG_ROWS_PER_WAVE][2];
-    unsigned pre_ok = 0;            // which of pre[] lie inside the image (applied when the patch is staged, so that
-                                    // nothing consumes the loads, and waits for them, before the next tile)
+    // Patch pixel i = tid + 256*q of the 19 x 35 patch: three floats, always loaded (clamped address); whether
+    // it lies inside the image is applied when the patch is staged, so that nothing consumes the loads, and
+    // waits for them, before the next tile.
+    float pre[IMG_LOADS][3];
+    unsigned pre_ok = 0;
     auto load_patch = [&](int t) {
         const int b = t / tiles_img;
         const int r = t - b * tiles_img;
         const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
-        const int y0 = 2 * ty * TH - 2, x0 = (2 * tx * TW - 2) * 3;
-        const int ix0 = x0 + lane, ix1 = x0 + lane + 64;
-        const bool okx0 = (unsigned)ix0 < (unsigned)row3, okx1 = lane + 64 < IM_W3 && (unsigned)ix1 < (unsigned)row3;
-        const int cx0 = min(max(ix0, 0), (int)row3 - 1), cx1 = min(max(ix1, 0), (int)row3 - 1);
+        const int y0 = 2 * ty * TH - 2, x0 = 2 * tx * TW - 2;
         pre_ok = 0;
+        int tv = tid;                       // opaque per call: keeps the per-thread patch coordinates from being
+        asm volatile("" : "+v"(tv));        // hoisted out of the tile loop into registers the weights need
 #pragma unroll
-        for (int q = 0; q < IMG_ROWS_PER_WAVE; ++q) {
-            const int iy = y0 + wave + 4 * q;
-            const bool oky = wave + 4 * q < IM_H && (unsigned)iy < (unsigned)p.H;
-            const float *rowp = p.img + ((long)b * p.H + min(max(iy, 0), p.H - 1)) * row3;     // always load (clamped), select later
-            pre[q][0] = rowp[cx0];
-            pre[q][1] = rowp[cx1];
-            pre_ok |= ((oky && okx0) ? 1u : 0u) << (2 * q) | ((oky && okx1) ? 2u : 0u) << (2 * q);
+        for (int q = 0; q < IMG_LOADS; ++q) {
+            const int i = min(tv + 256 * q, IM_PIX - 1);
+            const int rr = i / IM_W, cc = i - rr * IM_W;
+            const int iy = y0 + rr, ix = x0 + cc;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float *px = p.img + (((long)b * p.H + min(max(iy, 0), p.H - 1)) * p.W + min(max(ix, 0), p.W - 1)) * 3;
+            pre[q][0] = px[0]; pre[q][1] = px[1]; pre[q][2] = px[2];
+            pre_ok |= (ok ? 1u : 0u) << q;
         }
     };
+
+    // ---- per-lane constants of step 2 --------------------------------------------------------------
+    // Waves 0, 2 take the even patch columns px = 2*frow, waves 1, 3 the odd ones px = 2*frow + 1; patch rows
+    // py = (wave >> 1) + 2j.  Column 32 (17 pixels) is left over: wave 2 takes its rows 0..15, wave 3 row 16.
+    auto p_addr = [&](int kw, int py, int ox, int nb) {     // byte offset in P of this lane's 8 bytes of n-block nb
+        const int chunk = nb * 2 + (fq >> 1), sw = ((ox >> 3) & 1) << 1;
+        return ((kw * AP_H + py) * TW + ox) * 64 + ((chunk ^ sw) * 16) + (fq & 1) * 8;
+    };
+    const int par = wave & 1, pyw = wave >> 1;
+    const int rowsel = fq < 3 ? fq : 0;
+    const int px_l = 2 * frow + par;
+    const int rd_l = ((pyw + rowsel) * IM_PITCH + px_l) * 8;                   // + j * 2 * IM_PITCH * 8
+    const int wA0 = p_addr(par, pyw, frow, 0), wA1 = p_addr(par, pyw, frow, 1);   // + j * 2 * TW * 64
+    // even columns also feed P[2][.][ox - 1]; lane frow = 0 has no such slot and repeats its first store
+    // (same bytes, same address) instead, so that the second store needs no per-lane mask
+    const int wB0 = frow >= 1 ? p_addr(2, pyw, frow - 1, 0) : wA0, wB1 = frow >= 1 ? p_addr(2, pyw, frow - 1, 1) : wA1;
+    const bool doB = par == 0;
 
     // All weight loads retire here, and the compiler's wait-count model knows it (a builtin, not inline asm):
     // otherwise it assumes they may still be pending at the loop header and drains vmcnt, prefetch included,
     // before the first use of the weights in every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    // ---- 1. image patch -> LDS (bf16, 4 channels per pixel).  Runs at the END of the previous tile's
+    // iteration (all waves are past step 2 by then), so that the wait for the prefetched loads sits behind a
+    // known number of younger stores and the compiler can give it an exact vmcnt.
+    auto stage_patch = [&]() {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));        // see load_patch
+#pragma unroll
+    for (int q = 0; q < IMG_LOADS; ++q) {
+        const int i = tv + 256 * q;
+        const int rr = i / IM_W, cc = i - rr * IM_W;
+        const bool ok = (pre_ok >> q) & 1u;
+        uint2 o;
+        o.x = ok ? pack_bf16x2(pre[q][0], pre[q][1]) : 0u;
+        o.y = ok ? pack_bf16x2(pre[q][2], 0.0f) : 0u;
+        if (i < IM_PIX) *(uint2 *)(img + (rr * IM_PITCH + cc) * 8) = o;
+    }
+    };
     int t = blockIdx.x;
-    if (t < total) load_patch(t);
+    if (t < total) {
+        load_patch(t);
+        stage_patch();
+    }
     for (; t < total; t += gridDim.x) {
         const int b = t / tiles_img;
         const int r = t - b * tiles_img;
         const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
 
-        // ---- 1. image patch -> LDS (bf16) ---------------------------------------------------
-#pragma unroll
-        for (int q = 0; q < IMG_ROWS_PER_WAVE; ++q) {
-            const int rr = wave + 4 * q;
-            if (rr < IM_H) {
-                img[rr * IM_PITCH + lane] = ((pre_ok >> (2 * q)) & 1u) ? f32_to_bf16(pre[q][0]) : (unsigned short)0;
-                if (lane + 64 < IM_W3)
-                    img[rr * IM_PITCH + lane + 64] = ((pre_ok >> (2 * q + 1)) & 1u) ? f32_to_bf16(pre[q][1]) : (unsigned short)0;
-            }
-        }
         __syncthreads();            // patch visible; every wave is past step 3 of the previous tile
-        if (t + (int)gridDim.x < total) load_patch(t + gridDim.x);
+        // unconditional (the last iteration re-loads a valid tile for nobody): a conditional prefetch makes the
+        // compiler copy the loaded registers at the join, which waits for the loads right here
+        load_patch(min(t + (int)gridDim.x, total - 1));
 
         // ---- 2. conv A on the 17 x 33 patch -> P[kw][row][ox] --------------------------------
-        for (int pb = wave; pb < NBLK_A; pb += 4) {
-            const int pi = pb * 16 + frow;
-            const bool valid = pi < NPIX_A;
-            const int pp = valid ? pi : NPIX_A - 1;
-            const int py = pp / AP_W, px = pp - py * AP_W;
-            const int base = py * IM_PITCH + px * 3;
-            bf16x8 xf;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xf[i] = i < k_n ? (short)img[base + k_a + i * k_s] : (short)0;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 a[2];
-            a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], xf, z, 0, 0, 0);
-            a[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], xf, z, 0, 0, 0);
-            const int ay = 2 * oy0 - 1 + py, ax = 2 * ox0 - 1 + px;
-            const bool inimg = (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
-            const int oxe = px >> 1;
-            const int sw0 = ((oxe >> 3) & 1) << 1, sw2 = (((oxe - 1) >> 3) & 1) << 1;
+        auto conv_a_block = [&](const char *rd, bool in_img, char *a0, char *a1, bool do_a, char *b0, char *b1, bool do_b) {
+            const uint2 r0 = *(const uint2 *)rd, r1 = *(const uint2 *)(rd + 8);
+            const uint2 r2 = *(const uint2 *)(rd + 16), r3 = *(const uint2 *)(rd + 24);
+            const bf16x8 x0 = __builtin_bit_cast(bf16x8, u32x4{r0.x, r0.y, r1.x, r1.y});
+            const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{r2.x, r2.y, r3.x, r3.y});
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                f32x4 v = bias_act(a[nb], bias_s + nb * 16 + fq * 4, leaky_a);
-                uint2 o;
-                o.x = inimg ? pack_bf16x2(v[0], v[1]) : 0u;
-                o.y = inimg ? pack_bf16x2(v[2], v[3]) : 0u;
-                const int chunk = nb * 2 + (fq >> 1), half = (fq & 1) * 8;
-                if (valid) {
-                    if (px & 1) {
-                        *(uint2 *)(P + (((1 * AP_H + py) * TW + oxe) * 64) + ((chunk ^ sw0) * 16) + half) = o;
-                    } else {
-                        if (oxe < TW) *(uint2 *)(P + (((0 * AP_H + py) * TW + oxe) * 64) + ((chunk ^ sw0) * 16) + half) = o;
-                        if (oxe >= 1) *(uint2 *)(P + (((2 * AP_H + py) * TW + oxe - 1) * 64) + ((chunk ^ sw2) * 16) + half) = o;
-                    }
+                f32x4 a = *(const f32x4 *)(bias_s + nb * 16 + fq * 4);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8 *)(wa_s + nb * 1024), x0, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8 *)(wa_s + (2 + nb) * 1024), x1, a, 0, 0, 0);
+                const f32x4 v = act(a, slope_a);
+                uint2 o;                        // outside the image conv A's output is conv B's zero padding
+                o.x = in_img ? pack_bf16x2(v[0], v[1]) : 0u;
+                o.y = in_img ? pack_bf16x2(v[2], v[3]) : 0u;
+                if (do_a) *(uint2 *)(nb ? a1 : a0) = o;
+                if (do_b) *(uint2 *)(nb ? b1 : b0) = o;         // do_a, do_b are wave-uniform
+            }
+        };
+        {
+            const bool ax_ok = (unsigned)(2 * ox0 - 1 + px_l) < (unsigned)p.W;
+#pragma unroll
+            for (int j = 0; j < (AP_H + 1) / 2; ++j) {
+                const int py = pyw + 2 * j;                       // wave-uniform
+                if (py < AP_H) {
+                    const bool ay_ok = (unsigned)(2 * oy0 - 1 + py) < (unsigned)p.H;
+                    conv_a_block(img + rd_l + j * (2 * IM_PITCH * 8), ay_ok && ax_ok, P + wA0 + j * (2 * TW * 64),
+                                 P + wA1 + j * (2 * TW * 64), true, P + wB0 + j * (2 * TW * 64), P + wB1 + j * (2 * TW * 64), doB);
                 }
+            }
+            if (wave >= 2) {                                      // left-over column 32: lane frow <-> patch row py_x
+                int fr = frow;
+                asm volatile("" : "+v"(fr));
+                const int py_x = wave == 2 ? fr : 16;
+                const bool do_x = wave == 2 || frow == 0;
+                const int rd_x = ((py_x + rowsel) * IM_PITCH + 32) * 8;
+                const int dump_x = P_BYTES + IMG_BYTES + BIAS_BYTES + WC_BYTES + WA_BYTES + WB8_BYTES + lane * 8;
+                const int wX0 = do_x ? p_addr(2, py_x, 15, 0) : dump_x, wX1 = do_x ? p_addr(2, py_x, 15, 1) : dump_x;
+                const bool in_x = (unsigned)(2 * oy0 - 1 + py_x) < (unsigned)p.H && (unsigned)(2 * ox0 + 31) < (unsigned)p.W;
+                conv_a_block(img + rd_x, in_x, nullptr, nullptr, false, P + wX0, P + wX1, true);
             }
         }
         __syncthreads();
@@ -212,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         for (int mb = 0; mb < 2; ++mb) {
             f32x4 acc[4];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nb = 0; nb < 4; ++nb) acc[nb] = *(const f32x4 *)(bias_s + 32 + nb * 16 + fq * 4);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -220,24 +279,26 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
                     const int row = 2 * (2 * wave + mb) + kh;
                     const bf16x8 xf = *(const bf16x8 *)(P + ((kw * AP_H + row) * TW + frow) * 64 + slot);
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kh * 3 + kw][nb], xf, acc[nb], 0, 0, 0);
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const bf16x8 w = kh * 3 + kw < 8 ? wb[(kh * 3 + kw) & 7][nb] : *(const bf16x8 *)(wa_s + WA_BYTES + nb * 1024);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xf, acc[nb], 0, 0, 0);
+                    }
                 }
 
             // ---- epilogue B (+ conv C) --------------------------------------------------------
             const int oy = oy0 + 2 * wave + mb, ox = ox0 + frow;
             const bool ok = oy < p.Ho && ox < p.Wo;
-            const long pix = ((long)b * p.Ho + oy) * p.Wo + ox;
+            const unsigned pix = ok ? (unsigned)((b * p.Ho + oy) * p.Wo + ox) : 0x7fffffffu;
+            const unsigned off1 = ok ? (pix * p.out1_ld + cb) * 2u : 0xffffff00u;
             u32x4 y[2];
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                const f32x4 vx = bias_act(acc[2 * pr], bias_s + 32 + (2 * pr) * 16 + fq * 4, leaky_b);
-                const f32x4 vy = bias_act(acc[2 * pr + 1], bias_s + 32 + (2 * pr + 1) * 16 + fq * 4, leaky_b);
+                const f32x4 vx = act(acc[2 * pr], slope_b), vy = act(acc[2 * pr + 1], slope_b);
                 y[pr] = pair_lanes(vx, vy);
-                if (ok) *(u32x4 *)(p.out1 + (pix * p.out1_ld + pr * 32 + cb) * 2) = y[pr];
+                __builtin_amdgcn_raw_buffer_store_b128(y[pr], rsrc1, off1, pr * 64, 0);
             }
             if constexpr (HAS_C) {
-                f32x4 c2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                f32x4 c2[2] = {*(const f32x4 *)(bias_s + 96 + fq * 4), *(const f32x4 *)(bias_s + 96 + 16 + fq * 4)};
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -246,12 +307,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
                         const bf16x8 wc = *(const bf16x8 *)(wc_s + n * 128 + ((c ^ (n & 7)) * 16));
                         c2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc, __builtin_bit_cast(bf16x8, y[kb]), c2[nb], 0, 0, 0);
                     }
-                const f32x4 vx = bias_act(c2[0], bias_s + 96 + fq * 4, leaky_c);
-                const f32x4 vy = bias_act(c2[1], bias_s + 96 + 16 + fq * 4, leaky_c);
+                const f32x4 vx = act(c2[0], slope_c), vy = act(c2[1], slope_c);
                 const u32x4 o = pair_lanes(vx, vy);
-                if (ok) *(u32x4 *)(p.out2 + (pix * p.out2_ld + cb) * 2) = o;
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc2, ok ? (pix * p.out2_ld + cb) * 2u : 0xffffff00u, 0, 0);
             }
         }
+        stage_patch();          // next tile's patch (a repeat of the last tile's at the very end)
     }
 }
 
@@ -282,7 +343,10 @@ extern "C" int y3_conv_stem(const y3_stem_desc *d, const float *image, const flo
     a.Ho = (d->in_h - 2) / 2 + 1; a.Wo = (d->in_w - 2) / 2 + 1;        // pad top/left 1, VALID, stride 2
     a.tiles_y = (a.Ho + TH - 1) / TH; a.tiles_x = (a.Wo + TW - 1) / TW;
     a.n0_pad = d->n0_pad; a.k1_pad = d->k1_pad; a.k2_pad = d->k2_pad;
-    a.out1_ld = d->out1_ld; a.out2_ld = d->out2_ld; a.flags = d->flags;
+    a.out1_ld = d->out1_ld; a.out2_ld = d->out2_ld; a.flags = d->flags & 7;
+    const long bytes1 = (long)a.B * a.Ho * a.Wo * a.out1_ld * 2, bytes2 = (long)a.B * a.Ho * a.Wo * a.out2_ld * 2;
+    Y3_REQUIRE(bytes1 < 0xffff0000L && bytes2 < 0xffff0000L, Y3_E_INVALID, "stem: output of %ld bytes exceeds a 4 GiB buffer descriptor", bytes1);
+    a.out1_bytes = (unsigned)bytes1; a.out2_bytes = (unsigned)bytes2;
     const long total = (long)a.B * a.tiles_y * a.tiles_x;
     Y3_REQUIRE(total < 0x7fffffffL, Y3_E_INVALID, "stem: %ld tiles", total);
     const int grid = (int)(total < 512 ? total : 512);                 // two persistent workgroups per CU
