@@ -186,8 +186,10 @@ def test_conv_rejects_bad_arguments():
                                   (2, 20, 32, 256, 3, 1, True), (1, 9, 64, 128, 1, 1, True)],
                          ids=str)
 def test_conv_tile256_equals_tile128(case, dtype):
-    """The 256x256-tile variant (8 waves, two epilogue passes) against the oracle and against
-    the 128x128 variant (same k order per output -> identical bits)."""
+    """Every tile variant against the oracle, and against each other: variants that share an epilogue
+    sum each output in the same order -> identical bits.  Two epilogue families exist in bf16 mode:
+    the register epilogue (bias is the accumulator's initial value) and the LDS epilogue (bias added
+    last; ring kernels, fp32 mode, and debug bit 64)."""
     from yolo_amd import _lib
     lib = _lib.load()
     B, H, C, O, ks, stride, leaky = case
@@ -198,16 +200,25 @@ def test_conv_tile256_equals_tile128(case, dtype):
     r = rng.standard_normal((B,) + _ref(x, k, b, stride, leaky).shape[1:]).astype(np.float32)
     if dtype == "bf16":
         x, k, r = gpu_util.bf16_round(x), gpu_util.bf16_round(k), gpu_util.bf16_round(r)
-    outs = {}
-    try:
-        # low half: tile; high half: experiment bits (4 = ring-pipelined main loop, 2 = no interleave)
-        for tile in (128, 192, 256, (4 << 16) | 128, (4 << 16) | 256, (2 << 16) | 256):
-            _lib.check(lib.y3_set_conv_tile(tile))
-            outs[tile] = gpu_util.run_conv(x, k, b, stride, dtype, leaky=leaky, residual=r)
-    finally:
-        lib.y3_set_conv_tile(0)
+    # low half: tile; high half: experiment bits (4 = ring-pipelined main loop, 2 = no interleave, 64 = LDS epilogue)
+    reg_family = (128, 192, 256, (2 << 16) | 256)
+    lds_family = ((64 << 16) | 128, (64 << 16) | 192, (64 << 16) | 256, 257, (4 << 16) | 128, (4 << 16) | 256)
     want = _ref(x, k, b, stride, leaky, residual=r)
     tol = 1e-3 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(want))
-    assert np.all(np.abs(outs[256] - want) <= tol)
-    for tile in outs:           # same k order per accumulator in every variant -> identical bits
-        np.testing.assert_array_equal(outs[128], outs[tile])
+    outs = {}
+    try:
+        for res in (r, None):
+            for tile in reg_family + lds_family:
+                _lib.check(lib.y3_set_conv_tile(tile))
+                outs[tile] = gpu_util.run_conv(x, k, b, stride, dtype, leaky=leaky, residual=res)
+            w = want if res is not None else _ref(x, k, b, stride, leaky)
+            t = tol if res is not None else (1e-3 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(w)))
+            for tile in outs:
+                assert np.all(np.abs(outs[tile] - w) <= t), hex(tile)
+            for fam in (reg_family, lds_family):
+                for tile in fam:
+                    np.testing.assert_array_equal(outs[fam[0]], outs[tile])
+            if dtype == "fp32":      # one epilogue only
+                np.testing.assert_array_equal(outs[reg_family[0]], outs[lds_family[0]])
+    finally:
+        lib.y3_set_conv_tile(0)

@@ -41,6 +41,7 @@ struct ConvArgs {
     int Ho, Wo, HoWo, Cout8, out_ld, res_ld;
     int ks, stride, pad, Kpad, M, n_tiles, flags, step_tap, step_cin, sub_tap, sub_cin;
     FastDiv fd_howo, fd_wo;
+    unsigned out_bytes, res_bytes;     // extents for the buffer descriptors of the register epilogue
 };
 
 // Output row gm -> byte offset of its window's first input element and the 9-bit (1-bit for 1x1)
@@ -186,6 +187,86 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
     }
 }
 
+
+// Register epilogue (bf16 in, bf16 out, no upsampling): no LDS round trip, no barrier.  The accumulators were
+// initialised with the bias.  A lane holds 4 consecutive channels of one pixel per 16-channel block; pairs of
+// blocks are exchanged between lane rows r, r^1 with v_permlane16_swap so that each lane owns 8 consecutive
+// channels: the residual arrives as one 16-byte load per lane, is added in fp32 before the single bf16
+// rounding, and the result leaves as one 16-byte store (64 contiguous bytes per pixel and instruction).
+// Loads and stores go through buffer descriptors: lanes past the M or Cout edge get an out-of-range offset,
+// which the hardware ignores, so there is no branch around them.  All residual loads of the wave's tile are
+// issued before the first is used.
+constexpr int CONV_REG_EPILOGUE = 1 << 26;
+
+template <int TM, int TN, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&acc)[NI][MI], int m0, int n0, int lane, int wm, int wn) {
+    static_assert(NI % 2 == 0, "register epilogue pairs 16-channel blocks");
+    constexpr int NP2 = NI / 2;
+    const int frow = lane & 15, fq = lane >> 4;
+    const bool has_res = p.flags & Y3_CONV_RESIDUAL;
+    const float slope = (p.flags & Y3_CONV_LEAKY) ? 0.1f : 1.0f;
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? p.res : p.zeros), 0, has_res ? p.res_bytes : 0u, 0x00020000);
+    const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
+    const int nl = n0 + wn * TN + cb;                       // this lane's first channel in pair 0
+    constexpr unsigned OOB = 0xffffff00u;
+    u32x4 rv[MI][NP2];
+    if (has_res) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int gm = m0 + wm * TM + mi * 16 + frow;
+#pragma unroll
+            for (int pr = 0; pr < NP2; ++pr) {
+                const bool ok = gm < p.M && nl + pr * 32 < p.Cout8;
+                rv[mi][pr] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_res, ok ? ((unsigned)gm * (unsigned)p.res_ld + (unsigned)nl) * 2u : OOB, pr * 64, 0));
+            }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int gm = m0 + wm * TM + mi * 16 + frow;
+#pragma unroll
+        for (int pr = 0; pr < NP2; ++pr) {
+            const bool ok = gm < p.M && nl + pr * 32 < p.Cout8;
+            const unsigned off = ok ? ((unsigned)gm * (unsigned)p.out_ld + (unsigned)nl) * 2u : OOB;
+            f32x4 x = acc[2 * pr][mi], y = acc[2 * pr + 1][mi];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[j] = __builtin_amdgcn_fmed3f(x[j], slope * x[j], __builtin_inff());
+                y[j] = __builtin_amdgcn_fmed3f(y[j], slope * y[j], __builtin_inff());
+            }
+            u32x4 o;
+            if (has_res) {
+                float lo[4], hi[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {              // after the swap: lo = channels 0..3, hi = 4..7 of the lane's 8
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[j]), __float_as_uint(y[j]), false, false);
+                    lo[j] = __uint_as_float(sw[0]);
+                    hi[j] = __uint_as_float(sw[1]);
+                }
+                const u32x4 r = rv[mi][pr];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    lo[2 * j] += bf16_to_f32(r[j] & 0xffff);
+                    lo[2 * j + 1] += __uint_as_float(r[j] & 0xffff0000u);
+                    hi[2 * j] += bf16_to_f32(r[2 + j] & 0xffff);
+                    hi[2 * j + 1] += __uint_as_float(r[2 + j] & 0xffff0000u);
+                }
+                o[0] = pack_bf16x2(lo[0], lo[1]); o[1] = pack_bf16x2(lo[2], lo[3]);
+                o[2] = pack_bf16x2(hi[0], hi[1]); o[3] = pack_bf16x2(hi[2], hi[3]);
+            } else {
+                const unsigned x0 = pack_bf16x2(x[0], x[1]), x1 = pack_bf16x2(x[2], x[3]);
+                const unsigned y0 = pack_bf16x2(y[0], y[1]), y1 = pack_bf16x2(y[2], y[3]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, pr * 64, 0);
+        }
+    }
+}
+
 template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, bool INTERLEAVE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;   // threads
@@ -268,11 +349,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     };
 
     // ---- main loop ------------------------------------------------------------------------
+    const bool reg_epi = BF16 && (p.flags & CONV_REG_EPILOGUE);     // then the bias is the accumulators' initial value
     f32x4 acc[NI][MI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int ni = 0; ni < NI; ++ni) {
+        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (reg_epi) b0 = *(const f32x4 *)(p.bias + n0 + wn * TN + ni * 16 + (lane >> 4) * 4);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = b0;
+    }
 
     const int frow = lane & 15;
     const int fsw = (lane >> 1) & 7;
@@ -329,6 +414,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
     kstep(nk - 1, std::false_type{});
 
+    if (p.flags & (1 << 27)) {          // timing experiment: no epilogue (one store keeps the accumulators live)
+        float sacc = 0.f;
+        for (int ni = 0; ni < NI; ++ni) for (int mi = 0; mi < MI; ++mi) sacc += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
+        if (sacc == 123.456f) *(float *)p.out = sacc;
+        return;
+    }
+    if constexpr (BF16) {
+        if (reg_epi) {
+            conv_epilogue_regs<TM, TN, MI, NI>(p, acc, m0, n0, lane, wm, wn);
+            return;
+        }
+    }
     conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI>(p, acc, smem, m0, n0, tid, wm, wn);
 }
 
@@ -355,7 +452,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_ring_kernel
     constexpr int SLOT = (BM + BN) * 64;         // bytes per ring slot
     constexpr int NMF = NI * MI;
     static_assert(BM % LROWS == 0 && BN % LROWS == 0 && LROWS % 16 == 0, "tile vs loader");
-    static_assert(RING == 4, "wait counts below are written for a 4-slot ring");
+    static_assert(RING >= 3 && NP * (RING - 2) < 64, "ring depth vs vmcnt range");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -435,21 +532,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_ring_kernel
     int rd = 0;                 // ring slot of sub-tile s
     int wr = RING - 1;          // ring slot sub-tile s + RING - 1 goes to
     for (int s = 0; s < ns; ++s) {
-        // this wave's pieces of sub-tile s have landed once at most the younger sub-tiles' remain
+        // this wave's pieces of sub-tile s have landed once at most the younger sub-tiles' remain in flight
+        // (RING - 2 of them in the steady state, fewer at the tail)
         const int ahead = ns - 1 - s;
-        if (ahead >= 2) {
-            if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (ahead == 1) {
-            if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        constexpr auto wait_enc = [](int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); };
+        if (ahead >= RING - 2) __builtin_amdgcn_s_waitcnt(wait_enc(NP * (RING - 2)));
+        else if (RING > 3 && ahead == 1) __builtin_amdgcn_s_waitcnt(wait_enc(NP));
+        else __builtin_amdgcn_s_waitcnt(wait_enc(0));
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();      // everyone's pieces of s landed; slot wr (read in s-1) is free
         const bool pf = s + RING - 1 < ns;
         if (pf) stage_begin();
@@ -575,9 +665,8 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
 }
 
 
-template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS>
+template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS, int RING = 4>
 int launch_ring(ConvArgs a, int n_pad, hipStream_t stream) {
-    constexpr int RING = 4;
     constexpr int ring_bytes = RING * (BM + BN) * 64;
     constexpr int cs_bytes = EP_ROWS * (BN + 4) * 4;
     constexpr int lds = ring_bytes > cs_bytes ? ring_bytes : cs_bytes;
@@ -628,7 +717,7 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
             tile = (c256 <= c192 && c256 <= c128) ? 256 : (c192 <= c128 ? 192 : 128);
         }
     }
-    if (tile >= 192 && d->n_pad % 256 != 0) tile = 128;
+    if (tile >= 192 && tile != 257 && d->n_pad % 256 != 0) tile = 128;
     return tile;
 }
 
@@ -734,6 +823,7 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     if (g_conv_debug & 1) a.H = 0;             // timing experiment: every A tap reads the zero page
     if (g_conv_debug & 8) a.flags |= 1 << 29;  // timing experiment: no A loads at all (garbage results)
     if (g_conv_debug & 16) a.flags |= 1 << 28; // timing experiment: no B loads at all (garbage results)
+    if (g_conv_debug & 32) a.flags |= 1 << 27; // timing experiment: no epilogue (no results)
     const int bke = bf16 ? 64 : 32;
     a.n_tiles = 0;
     a.step_tap = bke / d->in_c;
@@ -743,6 +833,15 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     a.sub_tap = (bke / 2) / d->in_c;
     a.sub_cin = (bke / 2) % d->in_c;
     int v = conv_variant(d, M);
+    {   // register epilogue: bf16 -> bf16 without upsampling, tensors within a 4 GiB buffer descriptor
+        const long ob = M * (long)d->out_ld * 2, rb = M * (long)d->res_ld * 2;
+        a.out_bytes = a.res_bytes = 0;
+        if (bf16 && !out_f32 && !(d->flags & Y3_CONV_UPS2X) && ob < 0xffff0000L && rb < 0xffff0000L && !(g_conv_debug & 64)) {
+            a.flags |= CONV_REG_EPILOGUE;
+            a.out_bytes = (unsigned)ob;
+            a.res_bytes = (unsigned)rb;
+        }
+    }
     const bool ring = g_conv_debug & 4;            // ring-pipelined kernels (experiment switch)
     if (ring && v == 192) v = 256;
     if (ring && (v == 256 || v == 128)) {
@@ -752,12 +851,14 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
                         : launch_ring<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
     }
     if (bf16) {
+        if (v == 257) return launch_ring<true, 256, 128, 2, 2, 128, 3>(a, d->n_pad, stream);
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
         if (v == 192) return launch_igemm<true, 192, 256, 2, 4, 96>(a, d->n_pad, stream);
         if (v == 128) return launch_igemm<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
         if (v == 64) return launch_igemm<true, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
         return launch_igemm<true, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
     }
+    if (v == 257) return launch_ring<false, 256, 128, 2, 2, 128, 3>(a, d->n_pad, stream);
     if (v == 256) return launch_igemm<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
     if (v == 192) return launch_igemm<false, 192, 256, 2, 4, 96>(a, d->n_pad, stream);
     if (v == 128) return launch_igemm<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
@@ -779,7 +880,8 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     const long M = (long)d->batch * d->out_h * d->out_w;
     const int v = conv_variant(d, M);
     const char *k = (g_conv_debug & 4) && v >= 128 ? "conv_igemm_ring_kernel" : "conv_igemm_kernel";
-    if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
+    if (v == 257) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 128, 2, 2", t);
+    else if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
     else if (v == 192) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
     else if (v == 128) snprintf(buf, (size_t)len, "%s<%s, 128, 128, 2, 2", k, t);
     else if (v == 64) snprintf(buf, (size_t)len, "%s<%s, 128, 64, 2, 2", k, t);
@@ -791,7 +893,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
-    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256, Y3_E_INVALID, "conv tile %d (0, 128, 192 or 256)", tile);
+    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 257, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
     g_conv_tile = tile;
     return Y3_OK;
 }
