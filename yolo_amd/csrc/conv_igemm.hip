@@ -42,6 +42,7 @@ struct ConvArgs {
     int ks, stride, pad, Kpad, M, n_tiles, flags, step_tap, step_cin, sub_tap, sub_cin;
     FastDiv fd_howo, fd_wo;
     unsigned out_bytes, res_bytes;     // extents for the buffer descriptors of the register epilogue
+    int total_tiles;
 };
 
 // Output row gm -> byte offset of its window's first input element and the 9-bit (1-bit for 1x1)
@@ -289,7 +290,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // Workgroups are persistent when the grid is smaller than the tile count: tile = blockIdx.x, + gridDim.x, ...
+    // (gridDim.x is then a multiple of 8, so a workgroup's tiles keep its XCD).  The next tile's set-up and
+    // first loads overlap the previous tile's stores, which nothing waits for.
+    int pb = 0;                                  // pipeline buffer the next k-step reads
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    const int bid = xcd_remap(tile, p.total_tiles);
     const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of tile kt has landed
         __syncthreads();                                    // everyone's has; buffer (kt+1)&1 is free
         if constexpr (PF) stage_begin();
-        const char *As = smem + (kt & 1) * STAGE;
+        const char *As = smem + pb * STAGE;
         const char *Bs = As + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
                         for (int q = 0; q < NP; ++q)
                             if (j == (q * NMF) / NP) {
                                 if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
-                                piece(q, kt + 1, (kt + 1) & 1);
+                                piece(q, kt + 1, pb ^ 1);
                                 if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
                             }
                     }
@@ -406,11 +412,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
                 }
             }
         }
+        pb ^= 1;
     };
 
     stage_begin();
 #pragma unroll
-    for (int q = 0; q < NP; ++q) piece(q, 0, 0);
+    for (int q = 0; q < NP; ++q) piece(q, 0, pb);       // free: every wave is past the barrier of the last k-step
     for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
     kstep(nk - 1, std::false_type{});
 
@@ -418,15 +425,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
         float sacc = 0.f;
         for (int ni = 0; ni < NI; ++ni) for (int mi = 0; mi < MI; ++mi) sacc += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
         if (sacc == 123.456f) *(float *)p.out = sacc;
-        return;
+        continue;
     }
     if constexpr (BF16) {
         if (reg_epi) {
             conv_epilogue_regs<TM, TN, MI, NI>(p, acc, m0, n0, lane, wm, wn);
-            return;
+            continue;
         }
     }
     conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI>(p, acc, smem, m0, n0, tid, wm, wn);
+    __syncthreads();                             // the LDS epilogue's staging area overlaps the pipeline buffers
+    }
 }
 
 // ---- ring-pipelined variant -------------------------------------------------------------------
@@ -660,7 +669,11 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
     const int m_tiles = (a.M + BM - 1) / BM;
     const long nblk = (long)m_tiles * a.n_tiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv: grid of %ld blocks", nblk); return Y3_E_INVALID; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, a);
+    a.total_tiles = (int)nblk;
+    // persistent grid: as many workgroups as stay resident (LDS-limited), each walking several tiles
+    const long resident = 256L * (lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3));
+    const long grid = (g_conv_debug & 128) || nblk <= resident ? nblk : resident;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, stream, a);
     return y3_check_launch("conv_igemm");
 }
 
@@ -686,6 +699,7 @@ int launch_ring(ConvArgs a, int n_pad, hipStream_t stream) {
     const int m_tiles = (a.M + BM - 1) / BM;
     const long nblk = (long)m_tiles * a.n_tiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv: grid of %ld blocks", nblk); return Y3_E_INVALID; }
+    a.total_tiles = (int)nblk;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, a);
     return y3_check_launch("conv_igemm_ring");
 }

@@ -61,13 +61,39 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a) {
         const float *t = a.head[l] + ((long)b * a.d.grid_h[l] * gw + cell) * a.d.head_ld[l] + an * (5 + C);
 
         const float tb = j < 5 ? t[j] : 0.0f;                 // lanes 0..4: tx,ty,tw,th,tobj
-        float pc[6];
-        float pmax = -1.0f;
+        float tc[6];
+        float tmax = -__builtin_inff();
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int c = j + 16 * i;
-            pc[i] = -1.0f;
-            if (c < C) { pc[i] = sigmoidf_(t[5 + c]); pmax = fmaxf(pmax, pc[i]); }    // utils.py:87
+            tc[i] = c < C ? t[5 + c] : -__builtin_inff();
+            tmax = fmaxf(tmax, tc[i]);
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 16));
+        // The class probabilities are sigmoid(t_c) (utils.py:87) and only their maximum and the classes that
+        // attain it are used (utils.py:150-154).  sigmoid is increasing, so only logits close enough to the
+        // largest one that their fp32 sigmoid could still reach the maximum need the exact evaluation: a
+        // logit more than `win` below tmax has a true sigmoid at least 8 ulp below sigmoid(tmax)
+        // (win * sigmoid'(tmax) = 1e-6 * sigmoid(tmax)), the fp32 evaluation errs by 2-3.  Where sigmoid
+        // underflows (tmax < -80) every class is evaluated.
+        const float win = tmax < -80.0f ? __builtin_inff() : 1e-6f * (1.0f + __expf(tmax)) + 1e-6f * fabsf(tmax);
+        const float tcut = tmax - win;
+        unsigned need = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) need |= (j + 16 * i < C && tc[i] >= tcut) ? 1u << i : 0u;
+        float pc[6] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f, -1.0f};
+        float pmax = -1.0f;
+        while (__builtin_amdgcn_ballot_w64(need != 0)) {      // usually one round: the arg-max class of each box
+            const int i = need ? __ffs(need) - 1 : -1;
+            need &= need - 1;
+            float tv = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tv = i == k ? tc[k] : tv;
+            const float pv = sigmoidf_(tv);                                            // utils.py:87
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pc[k] = i == k ? pv : pc[k];
+            pmax = i >= 0 ? fmaxf(pmax, pv) : pmax;
         }
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, o, 16));  // utils.py:150
@@ -83,37 +109,34 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a) {
         for (int o = 8; o >= 1; o >>= 1) {
             m0 |= __shfl_xor(m0, o, 16); m1 |= __shfl_xor(m1, o, 16); m2 |= __shfl_xor(m2, o, 16);
         }
-        const float tx = __shfl(tb, 0, 16), ty = __shfl(tb, 1, 16), tw = __shfl(tb, 2, 16);
-        const float th = __shfl(tb, 3, 16), to = __shfl(tb, 4, 16);
 
-        // utils.py:84-92
-        const float bx = (sigmoidf_(tx) + (float)gx) * a.d.stride_x[l];
-        const float by = (sigmoidf_(ty) + (float)gy) * a.d.stride_y[l];
-        const float bw = expf(tw) * a.d.anchors[l][an][0];
-        const float bh = expf(th) * a.d.anchors[l][an][1];
-        const float conf = sigmoidf_(to);
-        // utils.py:118-126
-        const float hw = bw / 2.0f, hh = bh / 2.0f;
-        const float ymin = ((by - hh) - off_h / 2.0f) / scale;
-        const float xmin = ((bx - hw) - off_w / 2.0f) / scale;
-        const float ymax = ((by + hh) - off_h / 2.0f) / scale;
-        const float xmax = ((bx + hw) - off_w / 2.0f) / scale;
+        // utils.py:84-92: one transcendental per lane (lanes 0,1,4: sigmoid; lanes 2,3: exp), then shared
+        const bool is_wh = j == 2 || j == 3;
+        const float e = expf(is_wh ? tb : -tb);
+        const float f = is_wh ? e : 1.0f / (1.0f + e);
+        const float sx = __shfl(f, 0, 16), sy = __shfl(f, 1, 16), ew = __shfl(f, 2, 16);
+        const float eh = __shfl(f, 3, 16), conf = __shfl(f, 4, 16);
+        const float bx = (sx + (float)gx) * a.d.stride_x[l];
+        const float by = (sy + (float)gy) * a.d.stride_y[l];
+        const float bw = ew * a.d.anchors[l][an][0];
+        const float bh = eh * a.d.anchors[l][an][1];
+        // utils.py:118-126: lane j < 4 computes corner j = ymin, xmin, ymax, xmax
+        const bool isx = j & 1;
+        const float ctr = isx ? bx : by, half = (isx ? bw : bh) / 2.0f, off = (isx ? off_w : off_h) / 2.0f;
+        const float corner = (((j & 2) ? ctr + half : ctr - half) - off) / scale;
         const float score = conf * (pmax * 1.0f);                                      // utils.py:153-154
 
         if (live) {
             float v;
             switch (j) {
-                case 0: v = ymin; break;
-                case 1: v = xmin; break;
-                case 2: v = ymax; break;
-                case 3: v = xmax; break;
+                case 0: case 1: case 2: case 3: v = corner; break;
                 case 4: v = score; break;
                 case 5: v = __uint_as_float(m0); break;
                 case 6: v = __uint_as_float(m1); break;
                 default: v = __uint_as_float(m2); break;
             }
             if (j < 8) a.records[((long)b * N + p) * 8 + j] = v;
-            if (j == 0 && score >= thr) {                                              // inference.py:127
+            if (j == 4 && score >= thr) {                                              // inference.py:127
                 s_list[atomicAdd(&s_n, 1)] = p;
                 unsigned mm[3] = {m0, m1, m2};
                 for (int w = 0; w < 3; ++w)
