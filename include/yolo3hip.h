@@ -165,6 +165,16 @@ int y3_nms(const float *records, const int32_t *cand_idx, const int32_t *cand_co
            const int32_t *class_count, int batch, int boxes_per_image, int num_classes, int max_boxes,
            float iou_threshold, int32_t *kept_idx, int32_t *kept_rank, int32_t *kept_count,
            void *stream);
+/* Same result as y3_nms, faster: the candidates are first bucketed by class (one pass per image) into
+ * `workspace` (y3_nms_workspace_ints(batch, boxes_per_image) int32, caller-owned, contents don't matter),
+ * then every (image, class) pair of <= 128 candidates is suppressed by ONE wavefront with its candidates in
+ * registers, pairs of <= 1024 by one 256-thread workgroup (four candidates per thread, one barrier per round), both with the greedy
+ * order and predicate above; larger pairs take the LDS-resident workgroup kernel of y3_nms. */
+int64_t y3_nms_workspace_ints(int batch, int boxes_per_image);
+int y3_nms_bucketed(const float *records, const int32_t *cand_idx, const int32_t *cand_count,
+                    const int32_t *class_count, int batch, int boxes_per_image, int num_classes, int max_boxes,
+                    float iou_threshold, int32_t *workspace, int32_t *kept_idx, int32_t *kept_rank,
+                    int32_t *kept_count, void *stream);
 /* dynamic LDS the NMS kernel takes for this pool size (host-only helper). */
 int y3_nms_lds_bytes(int boxes_per_image);
 

@@ -135,6 +135,24 @@ def records_from_dense(boxes, scores, thr):
 
 
 def run_nms(per_image, num_classes, max_boxes, iou_thr, with_rank=True):
+    """Runs BOTH NMS entry points (y3_nms: workgroup kernel scanning the candidate list; y3_nms_bucketed:
+    class buckets + wavefront-per-pair kernel) on the same input, asserts that they agree bit for bit, and
+    returns the result.  per_image: list of (rec [N,8], cand [n], class_count [C]) with a common N."""
+    plain = _run_nms(per_image, num_classes, max_boxes, iou_thr, with_rank, bucketed=False)
+    fast = _run_nms(per_image, num_classes, max_boxes, iou_thr, with_rank, bucketed=True)
+    np.testing.assert_array_equal(plain["kept_count"], fast["kept_count"])
+    for b in range(plain["kept_count"].shape[0]):
+        for c in range(num_classes):
+            k = plain["kept_count"][b, c]
+            np.testing.assert_array_equal(plain["kept_idx"][b, c, :k], fast["kept_idx"][b, c, :k])
+            if with_rank:
+                np.testing.assert_array_equal(plain["kept_rank"][b, c, :k], fast["kept_rank"][b, c, :k])
+    for key in ("boxes", "scores", "classes", "count"):
+        np.testing.assert_array_equal(plain[key], fast[key])
+    return fast
+
+
+def _run_nms(per_image, num_classes, max_boxes, iou_thr, with_rank, bucketed):
     """per_image: list of (rec [N,8], cand [n], class_count [C]) with a common N."""
     lib = _lib.load()
     B = len(per_image)
@@ -151,9 +169,16 @@ def run_nms(per_image, num_classes, max_boxes, iou_thr, with_rank=True):
     kept_idx = torch.full((B, num_classes, max_boxes), -1, dtype=torch.int32, device="cuda")
     kept_rank = torch.full((B, num_classes, max_boxes), -1, dtype=torch.int32, device="cuda")
     kept_count = torch.full((B, num_classes), -1, dtype=torch.int32, device="cuda")
-    _lib.check(lib.y3_nms(rec.data_ptr(), cand_t.data_ptr(), cc_t.data_ptr(), clc_t.data_ptr(), B, N, num_classes,
-                          max_boxes, float(np.float32(iou_thr)), kept_idx.data_ptr(),
-                          kept_rank.data_ptr() if with_rank else None, kept_count.data_ptr(), stream()))
+    if bucketed:
+        wsp = torch.full((int(lib.y3_nms_workspace_ints(B, N)),), 12345, dtype=torch.int32, device="cuda")
+        _lib.check(lib.y3_nms_bucketed(rec.data_ptr(), cand_t.data_ptr(), cc_t.data_ptr(), clc_t.data_ptr(), B, N,
+                                       num_classes, max_boxes, float(np.float32(iou_thr)), wsp.data_ptr(),
+                                       kept_idx.data_ptr(), kept_rank.data_ptr() if with_rank else None,
+                                       kept_count.data_ptr(), stream()))
+    else:
+        _lib.check(lib.y3_nms(rec.data_ptr(), cand_t.data_ptr(), cc_t.data_ptr(), clc_t.data_ptr(), B, N, num_classes,
+                              max_boxes, float(np.float32(iou_thr)), kept_idx.data_ptr(),
+                              kept_rank.data_ptr() if with_rank else None, kept_count.data_ptr(), stream()))
     cap = num_classes * max_boxes
     ob = torch.zeros((B, cap, 4), dtype=torch.float32, device="cuda")
     os_ = torch.zeros((B, cap), dtype=torch.float32, device="cuda")

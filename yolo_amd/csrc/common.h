@@ -42,4 +42,11 @@ __device__ __forceinline__ float leaky01(float x) { return x > 0.0f ? x : 0.1f *
 // two instructions instead of three and no canonicalisation.
 __device__ __forceinline__ float leaky01_fast(float x) { return __builtin_amdgcn_fmed3f(x, 0.1f * x, __builtin_inff()); }
 
+// DPP moves within a row of 16 lanes: CTRL 0x120 + n = row_ror:n (rotate), 0x150 + n = row_newbcast:n
+// (lane n of the row to all its lanes).  No LDS traffic, one VALU instruction each.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }

@@ -27,6 +27,26 @@ struct DecodeArgs {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// 16-lane (one DPP row = one box group) all-reduce and broadcast without LDS traffic: row_ror:n rotates
+// within the row, so four rotate-and-combine steps leave the full result in every lane; row_newbcast:n
+// copies lane n of the row to all of its lanes.
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, __uint_as_float(dpp_u<0x128>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(dpp_u<0x124>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(dpp_u<0x122>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(dpp_u<0x121>(__float_as_uint(v))));
+    return v;
+}
+__device__ __forceinline__ unsigned row_or(unsigned v) {
+    v |= dpp_u<0x128>(v);
+    v |= dpp_u<0x124>(v);
+    v |= dpp_u<0x122>(v);
+    v |= dpp_u<0x121>(v);
+    return v;
+}
+template <int LANE>
+__device__ __forceinline__ float row_bcast(float v) { return __uint_as_float(dpp_u<0x150 + LANE>(__float_as_uint(v))); }
+
 __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a) {
     __shared__ int s_list[kChunk];
     __shared__ int s_hist[kMaxClasses];
@@ -60,17 +80,20 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a) {
         const int gy = cell / gw, gx = cell - gy * gw;
         const float *t = a.head[l] + ((long)b * a.d.grid_h[l] * gw + cell) * a.d.head_ld[l] + an * (5 + C);
 
-        const float tb = j < 5 ? t[j] : 0.0f;                 // lanes 0..4: tx,ty,tw,th,tobj
+        // all seven loads unconditional (clamped index, select afterwards): a load under a lane condition
+        // sits in its own branch with its own wait, which serialises seven memory round trips per box
+        const float tbr = t[min(j, 4)];                       // lanes 0..4: tx,ty,tw,th,tobj
         float tc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tc[i] = t[5 + min(j + 16 * i, C - 1)];
+        const float tb = j < 5 ? tbr : 0.0f;
         float tmax = -__builtin_inff();
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const int c = j + 16 * i;
-            tc[i] = c < C ? t[5 + c] : -__builtin_inff();
+            tc[i] = j + 16 * i < C ? tc[i] : -__builtin_inff();
             tmax = fmaxf(tmax, tc[i]);
         }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 16));
+        tmax = row_max(tmax);
         // The class probabilities are sigmoid(t_c) (utils.py:87) and only their maximum and the classes that
         // attain it are used (utils.py:150-154).  sigmoid is increasing, so only logits close enough to the
         // largest one that their fp32 sigmoid could still reach the maximum need the exact evaluation: a
@@ -95,8 +118,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a) {
             for (int k = 0; k < 6; ++k) pc[k] = i == k ? pv : pc[k];
             pmax = i >= 0 ? fmaxf(pmax, pv) : pmax;
         }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, o, 16));  // utils.py:150
+        pmax = row_max(pmax);                                                          // utils.py:150
         unsigned m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -105,17 +127,14 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a) {
                 if (i < 2) m0 |= 1u << c; else if (i < 4) m1 |= 1u << (c - 32); else m2 |= 1u << (c - 64);
             }
         }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) {
-            m0 |= __shfl_xor(m0, o, 16); m1 |= __shfl_xor(m1, o, 16); m2 |= __shfl_xor(m2, o, 16);
-        }
+        m0 = row_or(m0); m1 = row_or(m1); m2 = row_or(m2);
 
         // utils.py:84-92: one transcendental per lane (lanes 0,1,4: sigmoid; lanes 2,3: exp), then shared
         const bool is_wh = j == 2 || j == 3;
         const float e = expf(is_wh ? tb : -tb);
         const float f = is_wh ? e : 1.0f / (1.0f + e);
-        const float sx = __shfl(f, 0, 16), sy = __shfl(f, 1, 16), ew = __shfl(f, 2, 16);
-        const float eh = __shfl(f, 3, 16), conf = __shfl(f, 4, 16);
+        const float sx = row_bcast<0>(f), sy = row_bcast<1>(f), ew = row_bcast<2>(f);
+        const float eh = row_bcast<3>(f), conf = row_bcast<4>(f);
         const float bx = (sx + (float)gx) * a.d.stride_x[l];
         const float by = (sy + (float)gy) * a.d.stride_y[l];
         const float bw = ew * a.d.anchors[l][an][0];

@@ -17,6 +17,10 @@
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kWsHeader = 128;      // ints before a bucketed image's candidate list: start[0..C]
+constexpr int kSlots = 2;          // candidates per lane in nms_wave_kernel: up to 128 per (image, class) pair
+constexpr int kBSlots = 4;         // candidates per lane in nms_block_kernel (256 threads): up to 1024 per pair
+constexpr int kBlockMax = kThreads * kBSlots;
 
 __device__ __forceinline__ bool iou_gt(const f32x4 bi, const f32x4 bj, float thr) {
     const float ymin_i = fminf(bi[0], bi[2]), xmin_i = fminf(bi[1], bi[3]);
@@ -33,14 +37,46 @@ __device__ __forceinline__ bool iou_gt(const f32x4 bi, const f32x4 bj, float thr
     return iou > thr;
 }
 
+// Maximum of a 64-bit key over the wavefront, the same value in every lane: four rotate-and-compare DPP
+// steps inside each row of 16 lanes, then the four row results through v_readlane.  (A ds_bpermute
+// butterfly is twelve dependent LDS round trips, which dominated a greedy round.)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long max_dpp(unsigned long long v) {
+    const unsigned long long w = ((unsigned long long)dpp_u<CTRL>((unsigned)(v >> 32)) << 32) | dpp_u<CTRL>((unsigned)v);
+    return w > v ? w : v;
+}
+// The per-box half of iou_gt, hoisted: corners ordered, area computed once.  iou_gt_norm(norm(a), norm(b))
+// performs exactly iou_gt(a, b)'s operations on the same values, so the two agree bit for bit.
+struct NBox { float ymin, xmin, ymax, xmax, area; };
+__device__ __forceinline__ NBox norm_box(const f32x4 b) {
+    NBox n;
+    n.ymin = fminf(b[0], b[2]); n.xmin = fminf(b[1], b[3]);
+    n.ymax = fmaxf(b[0], b[2]); n.xmax = fmaxf(b[1], b[3]);
+    n.area = (n.ymax - n.ymin) * (n.xmax - n.xmin);
+    return n;
+}
+__device__ __forceinline__ bool iou_gt_norm(const NBox &i, const NBox &j, float thr) {
+    if (i.area <= 0.0f || j.area <= 0.0f) return false;
+    const float iymin = fmaxf(i.ymin, j.ymin), ixmin = fmaxf(i.xmin, j.xmin);
+    const float iymax = fminf(i.ymax, j.ymax), ixmax = fminf(i.xmax, j.xmax);
+    const float inter = fmaxf(iymax - iymin, 0.0f) * fmaxf(ixmax - ixmin, 0.0f);
+    const float iou = inter / (i.area + j.area - inter);
+    return iou > thr;
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = max_dpp<0x128>(v);
+    v = max_dpp<0x124>(v);
+    v = max_dpp<0x122>(v);
+    v = max_dpp<0x121>(v);
+    unsigned long long best = 0ull;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
-        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
-        v = w > v ? w : v;
+    for (int r = 0; r < 4; ++r) {
+        const unsigned long long w = ((unsigned long long)__builtin_amdgcn_readlane((unsigned)(v >> 32), 16 * r) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((unsigned)v, 16 * r);
+        best = w > best ? w : best;
     }
-    return v;
+    return best;
 }
 
 // key: high word = score bits (scores are >= +0, so the bit pattern is monotonic),
@@ -49,9 +85,13 @@ __device__ __forceinline__ unsigned long long make_key(float score, int idx) {
     return ((unsigned long long)__float_as_uint(score) << 32) | (unsigned)(~(unsigned)idx);
 }
 
+// ws (nullable): per image, class-bucketed candidate lists from nms_bucket_kernel.  With it, pairs of at most
+// small_limit candidates belong to nms_wave_kernel / nms_block_kernel and are skipped here, and the others copy their
+// bucket instead of scanning the image's whole candidate list.
 __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, const int *cand_idx, const int *cand_count,
                                                        const int *class_count, int B, int N, int C, int max_boxes,
-                                                       float thr, int *kept_idx, int *kept_rank, int *kept_count) {
+                                                       float thr, int *kept_idx, int *kept_rank, int *kept_count,
+                                                       const int *ws, int ws_stride, int small_limit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_list = (int *)smem;                                   // [N] pooled indices of this class
     unsigned char *s_alive = (unsigned char *)(s_list + N);      // [N] LDS-resident suppression state
@@ -66,9 +106,12 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
         int *kidx = kept_idx + (long)pair * max_boxes;
         const int ncls = class_count[pair];                      // wave-uniform
         if (ncls == 0) {
-            if (tid == 0) kept_count[pair] = 0;
+            if (tid == 0 && ws == nullptr) kept_count[pair] = 0;
             continue;
         }
+        const int *wsb = ws ? ws + (long)b * ws_stride : nullptr;
+        const bool bucketed = wsb && wsb[0] >= 0;                // block-uniform
+        if (bucketed && ncls <= small_limit) continue;           // nms_wave_kernel's or nms_block_kernel's
         __syncthreads();                                         // previous pair's LDS use is over
         if (tid == 0) s_n = 0;
         __syncthreads();
@@ -79,7 +122,13 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
         const int *cl = cand_idx + (long)b * N;
         const int cw = 5 + (c >> 5);
         const unsigned cbit = 1u << (c & 31);
-        for (int i0 = 0; i0 < nimg; i0 += kThreads) {
+        if (bucketed) {
+            const int *seg = wsb + kWsHeader + wsb[c];
+            const int nseg = min(ncls, N);
+            for (int i = tid; i < nseg; i += kThreads) { s_list[i] = seg[i]; s_alive[i] = 1; }
+            if (tid == 0) s_n = nseg;
+        }
+        for (int i0 = 0; i0 < (bucketed ? 0 : nimg); i0 += kThreads) {
             const int i = i0 + tid;
             bool mine = false;
             int idx = 0;
@@ -148,6 +197,218 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
     }
 }
 
+
+// ---- class bucketing: one workgroup per image --------------------------------------------------------
+// ws[b] = { start[0..C] (exclusive prefix sums of class_count), pad to kWsHeader, list[...] } where
+// list[start[c] .. start[c+1]) are the pooled indices of the image's candidates of class c (any order).
+// A candidate tied between classes is listed under each.  If that makes the lists longer than N
+// (degenerate all-tie inputs), ws[b][0] = -1 and the image is left to nms_kernel's scan.
+__global__ __launch_bounds__(1024) void nms_bucket_kernel(const float *records, const int *cand_idx, const int *cand_count,
+                                                          const int *class_count, int N, int C, int *ws, int ws_stride) {
+    __shared__ int s_start[128], s_fill[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 128) s_fill[tid] = 0;
+    if (tid == 0) {
+        int acc = 0;
+        for (int c = 0; c < C; ++c) { s_start[c] = acc; acc += class_count[b * C + c]; }
+        s_start[C] = acc;
+    }
+    __syncthreads();
+    int *wsb = ws + (long)b * ws_stride;
+    if (s_start[C] > N) {
+        if (tid == 0) wsb[0] = -1;
+        return;
+    }
+    if (tid <= C) wsb[tid] = s_start[tid];
+    const int nimg = min(cand_count[b], N);
+    const float *rec = records + (long)b * N * 8;
+    const int *cl = cand_idx + (long)b * N;
+    for (int i = tid; i < nimg; i += 1024) {
+        const int idx = cl[i];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            unsigned m = __float_as_uint(rec[(long)idx * 8 + 5 + w]);
+            while (m) {
+                const int c = w * 32 + __ffs(m) - 1;
+                m &= m - 1;
+                if (c < C) {
+                    const int pos = s_start[c] + atomicAdd(&s_fill[c], 1);
+                    if (pos < N) wsb[kWsHeader + pos] = idx;
+                }
+            }
+        }
+    }
+}
+
+// ---- one wavefront per (image, class) pair: candidates live in registers ----------------------------------
+// Same greedy order and suppression predicate as nms_kernel (largest (score, -index) key first, IoU > thr
+// strict), for pairs of at most 64 * kSlots candidates: no LDS, no workgroup barrier, the winner's box
+// travels by v_readlane.  Typical pairs have a handful of candidates, so thousands of pairs run at once.
+__global__ __launch_bounds__(kThreads) void nms_wave_kernel(const float *records, const int *class_count, const int *ws,
+                                                            int ws_stride, int B, int N, int C, int max_boxes, float thr,
+                                                            int *kept_idx, int *kept_rank, int *kept_count) {
+    const int lane = threadIdx.x & 63;
+    const int wave0 = (blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = (gridDim.x * kThreads) >> 6;
+    for (int pair = wave0; pair < B * C; pair += nwaves) {
+        const int b = pair / C, c = pair - b * C;
+        const int n = __builtin_amdgcn_readfirstlane(class_count[pair]);
+        if (n == 0) {
+            if (lane == 0) kept_count[pair] = 0;
+            continue;
+        }
+        const int *wsb = ws + (long)b * ws_stride;
+        if (n > 64 * kSlots || __builtin_amdgcn_readfirstlane(wsb[0]) < 0) continue;        // a workgroup kernel's
+        const int *list = wsb + kWsHeader + __builtin_amdgcn_readfirstlane(wsb[c]);
+        const float *rec = records + (long)b * N * 8;
+        const int ns = (n + 63) >> 6;             // slots in use (wave-uniform): the loops below skip the rest
+        f32x4 box[kSlots];
+        NBox nb[kSlots];
+        unsigned long long key[kSlots];
+        int idxs[kSlots];
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            key[k] = 0ull;
+            idxs[k] = 0x7fffffff;
+            box[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < ns) {
+                const int i = lane + 64 * k;
+                const int idx = list[i < n ? i : 0];
+                idxs[k] = i < n ? idx : 0x7fffffff;
+                box[k] = *(const f32x4 *)(rec + (long)idx * 8);
+                key[k] = i < n ? make_key(rec[(long)idx * 8 + 4], idx) : 0ull;
+            }
+            nb[k] = norm_box(box[k]);
+        }
+        int kept = 0;
+        int mine[4] = {0, 0, 0, 0};               // lane l holds kept index l + 64q in mine[q] (max_boxes <= 256)
+        int *kidx = kept_idx + (long)pair * max_boxes;
+        while (kept < max_boxes) {
+            unsigned long long best = key[0];
+#pragma unroll
+            for (int k = 1; k < kSlots; ++k)
+                if (k < ns) best = key[k] > best ? key[k] : best;
+            best = wave_max_u64(best);
+            if (best == 0ull) break;                                 // nothing alive (wave-uniform)
+            f32x4 cand = f32x4{0.f, 0.f, 0.f, 0.f};
+            bool own = false;
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k)
+                if (k < ns && key[k] == best) { cand = box[k]; own = true; key[k] = 0ull; }
+            const int src = __ffsll((unsigned long long)__ballot(own)) - 1;      // indices are unique: one owner
+            f32x4 win;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                win[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cand[q]), src));
+            const NBox nwin = norm_box(win);
+            const int win_idx = (int)(~(unsigned)best);
+            if (lane == 0) kidx[kept] = win_idx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((kept >> 6) == q && (kept & 63) == lane) mine[q] = win_idx;
+            ++kept;
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k)
+                if (k < ns) key[k] = iou_gt_norm(nb[k], nwin, thr) ? 0ull : key[k];
+        }
+        if (lane == 0) kept_count[pair] = kept;
+        if (kept_rank != nullptr) {               // tf nms_index: position in the order-preserving class-masked array
+            for (int kk = 0; kk < kept; ++kk) {
+                int v = mine[0];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) v = (kk >> 6) == q ? mine[q] : v;
+                const int kid = __builtin_amdgcn_readlane(v, kk & 63);
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < kSlots; ++k)
+                    if (k < ns) cnt += __popcll((unsigned long long)__ballot(idxs[k] < kid));
+                if (lane == 0) kept_rank[(long)pair * max_boxes + kk] = cnt;
+            }
+        }
+    }
+}
+
+// ---- one 256-thread workgroup per (image, class) pair of 64*kSlots < n <= 1024 candidates ----------------
+// Up to four candidates per thread, in registers.  One barrier per round: every wave publishes its best key
+// AND that candidate's box; after the barrier each thread picks the winning wave's pair from LDS (buffers
+// alternate between rounds).  Same order and predicate as the other two kernels.
+__global__ __launch_bounds__(kThreads) void nms_block_kernel(const float *records, const int *class_count, const int *ws,
+                                                             int ws_stride, int B, int N, int C, int max_boxes, float thr,
+                                                             int *kept_idx, int *kept_rank, int *kept_count) {
+    __shared__ unsigned long long s_key[2][4];
+    __shared__ f32x4 s_box[2][4];
+    __shared__ int s_kept[kThreads], s_rank[kThreads];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int pair = blockIdx.x; pair < B * C; pair += gridDim.x) {
+        const int b = pair / C, c = pair - b * C;
+        const int n = class_count[pair];
+        const int *wsb = ws + (long)b * ws_stride;
+        if (n <= 64 * kSlots || n > kBlockMax || wsb[0] < 0) continue;         // block-uniform
+        const int *list = wsb + kWsHeader + wsb[c];
+        const float *rec = records + (long)b * N * 8;
+        const int ns = (n + kThreads - 1) / kThreads;             // slots in use (block-uniform)
+        f32x4 box[kBSlots];
+        NBox nb[kBSlots];
+        unsigned long long key[kBSlots];
+        int idxs[kBSlots];
+#pragma unroll
+        for (int k = 0; k < kBSlots; ++k) {
+            const int i = tid + kThreads * k;
+            const int idx = list[i < n ? i : 0];
+            idxs[k] = i < n ? idx : 0x7fffffff;
+            box[k] = *(const f32x4 *)(rec + (long)idx * 8);
+            nb[k] = norm_box(box[k]);
+            key[k] = i < n ? make_key(rec[(long)idx * 8 + 4], idx) : 0ull;
+        }
+        int *kidx = kept_idx + (long)pair * max_boxes;
+        int kept = 0;
+        __syncthreads();                                         // previous pair's LDS use is over
+        while (kept < max_boxes) {
+            unsigned long long lbest = key[0];
+#pragma unroll
+            for (int k = 1; k < kBSlots; ++k) lbest = key[k] > lbest ? key[k] : lbest;
+            const unsigned long long wbest = wave_max_u64(lbest);
+            if (wbest != 0ull && lbest == wbest) {               // indices are unique: one lane, one slot
+                f32x4 cand = box[0];
+#pragma unroll
+                for (int k = 1; k < kBSlots; ++k) cand = key[k] == wbest ? box[k] : cand;
+                s_box[kept & 1][wave] = cand;
+            }
+            if (lane == 0) s_key[kept & 1][wave] = wbest;
+            __syncthreads();
+            unsigned long long best = s_key[kept & 1][0];
+            int ww = 0;
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const unsigned long long v = s_key[kept & 1][w]; if (v > best) { best = v; ww = w; } }
+            if (best == 0ull) break;                             // nothing alive (block-uniform)
+            const NBox win = norm_box(s_box[kept & 1][ww]);
+            if (tid == 0) { const int wi = (int)(~(unsigned)best); kidx[kept] = wi; s_kept[kept] = wi; }
+            ++kept;
+#pragma unroll
+            for (int k = 0; k < kBSlots; ++k) {
+                // branch-free on purpose: as `if (alive && (key == best || iou)) key = 0` this update was
+                // dropped by hipcc 7.2 for some lanes (caught by the parity test against y3_nms)
+                if (k < ns) {                       // block-uniform
+                    const bool kill = key[k] == best || iou_gt_norm(nb[k], win, thr);
+                    key[k] = kill ? 0ull : key[k];
+                }
+            }
+        }
+        if (tid == 0) kept_count[pair] = kept;
+        if (kept_rank != nullptr) {
+            s_rank[tid] = 0;
+            __syncthreads();
+            for (int kk = 0; kk < kept; ++kk) {
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < kBSlots; ++k) cnt += __popcll((unsigned long long)__ballot(idxs[k] < s_kept[kk]));
+                if (lane == 0 && cnt) atomicAdd(&s_rank[kk], cnt);
+            }
+            __syncthreads();
+            if (tid < kept) kept_rank[(long)pair * max_boxes + tid] = s_rank[tid];
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void pack_kernel(const float *records, const int *kept_idx, const int *kept_count,
                                                         int N, int C, int max_boxes, float *out_boxes,
                                                         float *out_scores, int *out_classes, int *out_count) {
@@ -178,9 +439,9 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(const float *records, co
 
 extern "C" int y3_nms_lds_bytes(int boxes_per_image) { return boxes_per_image * 5 + 16; }
 
-extern "C" int y3_nms(const float *records, const int32_t *cand_idx, const int32_t *cand_count,
-                      const int32_t *class_count, int batch, int boxes_per_image, int num_classes, int max_boxes,
-                      float iou_threshold, int32_t *kept_idx, int32_t *kept_rank, int32_t *kept_count, void *stream) {
+static int launch_nms(const float *records, const int32_t *cand_idx, const int32_t *cand_count, const int32_t *class_count,
+                      int batch, int boxes_per_image, int num_classes, int max_boxes, float iou_threshold, int32_t *workspace,
+                      int32_t *kept_idx, int32_t *kept_rank, int32_t *kept_count, hipStream_t stream) {
     Y3_REQUIRE(records && cand_idx && cand_count && class_count && kept_idx && kept_count, Y3_E_INVALID, "nms: null pointer");
     Y3_REQUIRE(batch > 0 && boxes_per_image > 0 && num_classes > 0 && num_classes <= 96, Y3_E_INVALID, "nms: bad shape");
     Y3_REQUIRE(max_boxes > 0 && max_boxes <= kThreads, Y3_E_INVALID, "nms: max_boxes %d (1..%d)", max_boxes, kThreads);
@@ -197,12 +458,46 @@ extern "C" int y3_nms(const float *records, const int32_t *cand_idx, const int32
         }
         attr_dev = dev; attr_lds = 150 * 1024;
     }
+    const int ws_stride = boxes_per_image + kWsHeader;
+    const int pairs = batch * num_classes;
+    if (workspace) {
+        hipLaunchKernelGGL(nms_bucket_kernel, dim3(batch), dim3(1024), 0, stream, records, cand_idx, cand_count, class_count,
+                           boxes_per_image, num_classes, workspace, ws_stride);
+        int wblocks = (pairs + 3) / 4;
+        if (wblocks > 256 * 8) wblocks = 256 * 8;
+        hipLaunchKernelGGL(nms_wave_kernel, dim3(wblocks), dim3(kThreads), 0, stream, records, class_count, workspace, ws_stride,
+                           batch, boxes_per_image, num_classes, max_boxes, iou_threshold, kept_idx, kept_rank, kept_count);
+        hipLaunchKernelGGL(nms_block_kernel, dim3(pairs), dim3(kThreads), 0, stream, records, class_count,
+                           workspace, ws_stride, batch, boxes_per_image, num_classes, max_boxes, iou_threshold, kept_idx,
+                           kept_rank, kept_count);
+    }
     const int per_cu = lds > 0 ? (155 * 1024) / (lds + 1024) : 8;
     int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
-    if (blocks > batch * num_classes) blocks = batch * num_classes;
-    hipLaunchKernelGGL(nms_kernel, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, records, cand_idx, cand_count,
-                       class_count, batch, boxes_per_image, num_classes, max_boxes, iou_threshold, kept_idx, kept_rank, kept_count);
+    if (blocks > pairs) blocks = pairs;
+    hipLaunchKernelGGL(nms_kernel, dim3(blocks), dim3(kThreads), lds, stream, records, cand_idx, cand_count,
+                       class_count, batch, boxes_per_image, num_classes, max_boxes, iou_threshold, kept_idx, kept_rank, kept_count,
+                       workspace, ws_stride, kBlockMax);
     return y3_check_launch("nms");
+}
+
+extern "C" int y3_nms(const float *records, const int32_t *cand_idx, const int32_t *cand_count,
+                      const int32_t *class_count, int batch, int boxes_per_image, int num_classes, int max_boxes,
+                      float iou_threshold, int32_t *kept_idx, int32_t *kept_rank, int32_t *kept_count, void *stream) {
+    return launch_nms(records, cand_idx, cand_count, class_count, batch, boxes_per_image, num_classes, max_boxes, iou_threshold,
+                      nullptr, kept_idx, kept_rank, kept_count, (hipStream_t)stream);
+}
+
+extern "C" int64_t y3_nms_workspace_ints(int batch, int boxes_per_image) {
+    return (int64_t)batch * (boxes_per_image + kWsHeader);
+}
+
+extern "C" int y3_nms_bucketed(const float *records, const int32_t *cand_idx, const int32_t *cand_count,
+                               const int32_t *class_count, int batch, int boxes_per_image, int num_classes, int max_boxes,
+                               float iou_threshold, int32_t *workspace, int32_t *kept_idx, int32_t *kept_rank,
+                               int32_t *kept_count, void *stream) {
+    Y3_REQUIRE(workspace != nullptr, Y3_E_INVALID, "nms_bucketed: null workspace");
+    return launch_nms(records, cand_idx, cand_count, class_count, batch, boxes_per_image, num_classes, max_boxes, iou_threshold,
+                      workspace, kept_idx, kept_rank, kept_count, (hipStream_t)stream);
 }
 
 extern "C" int y3_pack_outputs(const float *records, const int32_t *kept_idx, const int32_t *kept_count, int batch,

@@ -81,7 +81,8 @@ class PostProcessor(object):
                       kept_rank=torch.empty((B, C, K), **i32) if self.with_rank else None,
                       out_boxes=torch.empty((B, C * K, 4), **f32), out_scores=torch.empty((B, C * K), **f32),
                       out_classes=torch.empty((B, C * K), **i32), out_count=torch.empty(B, **i32),
-                      letterbox=torch.empty((B, 4), **f32))
+                      letterbox=torch.empty((B, 4), **f32),
+                      nms_ws=torch.empty(int(_lib.load().y3_nms_workspace_ints(B, N)), **i32))
             self._ws[key] = ws
         return ws
 
@@ -135,9 +136,10 @@ class PostProcessor(object):
                                  ws["records"].data_ptr(), ws["cand_idx"].data_ptr(), cand_count.data_ptr(),
                                  class_count.data_ptr(), stream))
         rank_ptr = ws["kept_rank"].data_ptr() if self.with_rank else None
-        _lib.check(lib.y3_nms(ws["records"].data_ptr(), ws["cand_idx"].data_ptr(), cand_count.data_ptr(),
-                              class_count.data_ptr(), B, N, C, self.max_boxes, self.iou_threshold,
-                              ws["kept_idx"].data_ptr(), rank_ptr, ws["kept_count"].data_ptr(), stream))
+        _lib.check(lib.y3_nms_bucketed(ws["records"].data_ptr(), ws["cand_idx"].data_ptr(), cand_count.data_ptr(),
+                                       class_count.data_ptr(), B, N, C, self.max_boxes, self.iou_threshold,
+                                       ws["nms_ws"].data_ptr(), ws["kept_idx"].data_ptr(), rank_ptr,
+                                       ws["kept_count"].data_ptr(), stream))
         _lib.check(lib.y3_pack_outputs(ws["records"].data_ptr(), ws["kept_idx"].data_ptr(), ws["kept_count"].data_ptr(),
                                        B, N, C, self.max_boxes, ws["out_boxes"].data_ptr(), ws["out_scores"].data_ptr(),
                                        ws["out_classes"].data_ptr(), ws["out_count"].data_ptr(), stream))
