@@ -234,12 +234,13 @@ class Network(object):
             self._plans[key] = cp
         return cp
 
-    def forward(self, images, chunk=None, trace=None):
+    def forward(self, images, chunk=None, trace=None, trace_filter=None):
         """images: float32 NHWC [B,H,W,3] on this network's device, values as the reference
         feeds them (image/255, inference.py:242).  Returns the head tensors (fp32,
         [B,g,g,3*(C+5)] views, coarse -> fine).  `chunk` splits the batch into sub-batches
         that run back to back through the whole plan.  `trace`, if a list, receives
-        (op, start_event, end_event) for every launch (HIP events on the launch stream)."""
+        (op, start_event, end_event) for every launch (HIP events on the launch stream), or only for
+        the launches trace_filter(op) selects (an event pair costs ~3 us of stream time)."""
         if not isinstance(images, torch.Tensor):
             images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
         if images.dim() != 4 or images.shape[-1] != 3:
@@ -264,6 +265,11 @@ class Network(object):
                         _lib.check(rc)
             else:
                 for op, launch in zip(cp.plan.ops, cp.launchers):
+                    if trace_filter is not None and not trace_filter(op):
+                        rc = launch(env)
+                        if rc:
+                            _lib.check(rc)
+                        continue
                     e0 = torch.cuda.Event(enable_timing=True)
                     e1 = torch.cuda.Event(enable_timing=True)
                     e0.record()
