@@ -140,6 +140,9 @@ int y3_decode(const y3_decode_desc *desc, const float *head0, const float *head1
               const float *letterbox, float *records, int32_t *cand_idx, int32_t *cand_count,
               int32_t *class_count, void *stream);
 
+/* Test knob: 1 = always the 16-lanes-per-box decode kernel, 0 = automatic (lane-per-box when shapes allow). */
+int y3_decode_variant(int v);
+
 /* Dense forms kept for API parity with the reference's helper functions. */
 /* get_head (utils/utils.py:43-96) for one scale: xy,wh [cells*A*2], conf [cells*A], cls [cells*A*C]. */
 int y3_get_head(const float *head, int batch, int grid_h, int grid_w, int head_ld, int num_anchors,

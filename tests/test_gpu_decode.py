@@ -103,3 +103,42 @@ def test_head_with_plain_contiguous_layout_and_bad_channels():
         pp([out[..., :250]], (416, 416))
     with pytest.raises(ValueError):
         inference.predict([out, out], TINY, 20, (416, 416), (416, 416))
+
+
+@pytest.mark.parametrize("grids,anchors,size,scale", [((19, 38, 76), COCO, 608, 1.5), ((13, 26), TINY, 416, 1.5),
+                                                      ((13, 26, 52), COCO, 416, 12.0), ((7, 9, 21), COCO, 224, 60.0)])
+def test_lane_per_box_decode_equals_16_lane_decode(grids, anchors, size, scale):
+    """The network hands y3_decode heads whose cells are 256 floats apart: that layout takes the lane-per-box
+    kernel (LDS-DMA staging, exact sigmoid only near the class maximum).  It must reproduce the
+    16-lanes-per-box kernel bit for bit -- records, candidate set and per-class counts -- including
+    saturated sigmoids (scale 12: many classes tie at 1.0) and underflowing ones (scale 60)."""
+    from yolo_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(int(size + scale))
+    B = 2
+    full = [torch.from_numpy((rng.standard_normal((B, g, g, 256)) * scale).astype(np.float32)).cuda() for g in grids]
+    if scale > 50:
+        full[0][0, 0, 0, 5:85] = -95.0                       # every class underflows: all tie at sigmoid = 0
+        full[1][1, 2, 3, 90:170] = 30.0                      # every class saturates: all tie at 1
+    heads = [t[..., :255] for t in full]
+    outs = []
+    try:
+        for variant in (1, 0):
+            lib.y3_decode_variant(variant)
+            pp = PostProcessor(anchors, 80, (size, size), score_threshold=0.3)
+            det = pp(heads, (size - 7, size + 40))
+            torch.cuda.synchronize()
+            ws = list(pp._ws.values())[0]
+            n = det.cand_count.cpu().numpy()
+            cand = [np.sort(ws["cand_idx"][b, :n[b]].cpu().numpy()) for b in range(B)]
+            outs.append((det.records.cpu().numpy().copy(), n.copy(), cand, ws["counts"].cpu().numpy().copy(),
+                         det.kept_idx.cpu().numpy().copy(), det.kept_count.cpu().numpy().copy()))
+    finally:
+        lib.y3_decode_variant(0)
+    a, b_ = outs
+    np.testing.assert_array_equal(a[0].view(np.uint32), b_[0].view(np.uint32))
+    np.testing.assert_array_equal(a[1], b_[1])
+    for x, y in zip(a[2], b_[2]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[3], b_[3])
+    np.testing.assert_array_equal(a[5], b_[5])

@@ -12,6 +12,8 @@
 
 namespace {
 
+bool g_decode_force_v1 = false;      // test knob: y3_decode_variant
+
 constexpr int kThreads = 256;
 constexpr int kChunk = 1024;      // boxes per block
 constexpr int kMaxClasses = 96;   // 3 x 32-bit class mask
@@ -172,6 +174,184 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a) {
     for (int i = tid; i < n; i += kThreads) a.cand_idx[(long)b * N + base + i] = s_list[i];
 }
 
+
+// ---- decode, one lane per box ----------------------------------------------------------------------------
+// A wavefront takes 16 consecutive grid cells of one scale (48 boxes): their head values, one contiguous run
+// of 16 * head_ld floats, are copied to LDS by LDS-DMA (16-byte coalesced, no registers), one cell per
+// instruction with the cells 16 bytes apart in LDS so that lanes reading the same element of different
+// cells spread over the banks.  Lane (cell i, anchor a) then walks its own 5 + C values: the class maximum
+// costs one ds_read + one v_max per class per 48 boxes instead of a cross-lane reduction per box, and the
+// exact sigmoid is evaluated only for logits that can reach the maximum (see `win` below).
+// Same arithmetic, in the same order, as decode_kernel: the two produce identical records.
+constexpr int kCellsPerWave = 16;
+constexpr int kCellPitch = 1024 + 16;                       // bytes between cells in LDS (head_ld <= 256)
+constexpr int kWaveLds = kCellsPerWave * kCellPitch;
+
+struct DecodeArgs2 {
+    DecodeArgs a;
+    int groups[3];          // 16-cell groups per scale
+    int groups_per_image, slices;
+};
+
+__device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(kThreads) void decode_lane_kernel(const DecodeArgs2 q) {
+    const DecodeArgs &a = q.a;
+    __shared__ __attribute__((aligned(16))) char s_head[4 * kWaveLds];
+    __shared__ int s_list[4 * 48 * 8];       // candidates of this block (flushed when nearly full)
+    __shared__ int s_hist[kMaxClasses];
+    __shared__ int s_n, s_base;
+
+    const int b = blockIdx.y;
+    const int N = a.d.boxes_per_image;
+    const int C = a.d.num_classes, A = a.d.num_anchors, E = 5 + C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < kMaxClasses) s_hist[tid] = 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+
+    const float scale = a.letterbox[b * 4 + 0];
+    const float off_h = a.letterbox[b * 4 + 1];
+    const float off_w = a.letterbox[b * 4 + 2];
+    const float thr = a.d.score_threshold;
+    char *my = s_head + wave * kWaveLds;
+    const int ci = lane / A, an = lane - ci * A;              // this lane's cell within the group, anchor
+    const bool has_box = ci < kCellsPerWave;
+
+    for (int t = (blockIdx.x * 4 + wave); t < q.groups_per_image; t += q.slices * 4) {
+        const int l = t >= q.groups[0] + q.groups[1] ? 2 : (t >= q.groups[0] ? 1 : 0);
+        const int g = t - (l == 2 ? q.groups[0] + q.groups[1] : (l == 1 ? q.groups[0] : 0));
+        const int gw = a.d.grid_w[l], ncell = a.d.grid_h[l] * gw, ld = a.d.head_ld[l];
+        const int cell0 = g * kCellsPerWave;
+        const float *src = a.head[l] + ((long)b * ncell + cell0) * ld;
+        const int ncopy = min(kCellsPerWave, ncell - cell0);
+        // the previous group's LDS reads of this wave are complete: they were consumed by VALU
+        for (int i = 0; i < ncopy; ++i) {                      // wave-uniform trip count
+            const int off = lane * 16 < ld * 4 ? lane * 16 : 0;     // lanes past the cell repeat its first chunk
+            lds_dma16((const char *)(src + (long)i * ld) + off, my + i * kCellPitch);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        const int cell = cell0 + ci;
+        const bool live = has_box && cell < ncell;
+        const float *tl = (const float *)(my + (live ? ci : 0) * kCellPitch) + an * E;
+        // (unrolled by 16: the LDS reads of a batch are in flight together instead of one round trip per class)
+        float tmax = -__builtin_inff();
+        {
+            int c = 0;
+            for (; c + 16 <= C; c += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = tl[5 + c + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tmax = fmaxf(tmax, v[u]);
+            }
+            for (; c < C; ++c) tmax = fmaxf(tmax, tl[5 + c]);
+        }
+        // sigmoid is increasing, so only logits close enough to the largest one that their fp32 sigmoid could
+        // still reach the maximum need the exact evaluation: a logit more than `win` below tmax has a true
+        // sigmoid at least 8 ulp below sigmoid(tmax) (win * sigmoid'(tmax) = 1e-6 * sigmoid(tmax)); the fp32
+        // evaluation errs by 2-3.  Where sigmoid underflows (tmax < -80) every class is evaluated.
+        const float win = tmax < -80.0f ? __builtin_inff() : 1e-6f * (1.0f + __expf(tmax)) + 1e-6f * fabsf(tmax);
+        const float tcut = tmax - win;
+        unsigned need[3] = {0u, 0u, 0u};
+        {
+            int c = 0;
+            for (; c + 16 <= C; c += 16) {               // 16 never straddles a 32-bit mask word
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = tl[5 + c + u];
+                unsigned bits = 0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) bits |= (v[u] >= tcut ? 1u : 0u) << u;
+                const unsigned sh = bits << (c & 31);
+                if ((c >> 5) == 0) need[0] |= sh; else if ((c >> 5) == 1) need[1] |= sh; else need[2] |= sh;
+            }
+            for (; c < C; ++c) {
+                const unsigned bit = (tl[5 + c] >= tcut ? 1u : 0u) << (c & 31);
+                if ((c >> 5) == 0) need[0] |= bit; else if ((c >> 5) == 1) need[1] |= bit; else need[2] |= bit;
+            }
+        }
+        if (!live) need[0] = need[1] = need[2] = 0u;
+        // exact sigmoid of the needed classes (usually one per box), written back over the logit
+        float pmax = -1.0f;
+        unsigned todo[3] = {need[0], need[1], need[2]};
+        float *tw = (float *)(my + (live ? ci : 0) * kCellPitch) + an * E;
+        while (__builtin_amdgcn_ballot_w64((todo[0] | todo[1] | todo[2]) != 0u)) {
+            const int w = todo[0] ? 0 : (todo[1] ? 1 : 2);
+            const unsigned m = w == 0 ? todo[0] : (w == 1 ? todo[1] : todo[2]);
+            if (m) {
+                const int c = w * 32 + __ffs(m) - 1;
+                const float pv = sigmoidf_(tw[5 + c]);                                  // utils.py:87
+                tw[5 + c] = pv;
+                pmax = fmaxf(pmax, pv);                                                // utils.py:150
+                if (w == 0) todo[0] = m & (m - 1); else if (w == 1) todo[1] = m & (m - 1); else todo[2] = m & (m - 1);
+            }
+        }
+        unsigned m0 = 0, m1 = 0, m2 = 0;
+        todo[0] = need[0]; todo[1] = need[1]; todo[2] = need[2];
+        while (__builtin_amdgcn_ballot_w64((todo[0] | todo[1] | todo[2]) != 0u)) {
+            const int w = todo[0] ? 0 : (todo[1] ? 1 : 2);
+            const unsigned m = w == 0 ? todo[0] : (w == 1 ? todo[1] : todo[2]);
+            if (m) {
+                const int bit = __ffs(m) - 1;
+                if (tw[5 + w * 32 + bit] >= pmax) {                                    // utils.py:151
+                    if (w == 0) m0 |= 1u << bit; else if (w == 1) m1 |= 1u << bit; else m2 |= 1u << bit;
+                }
+                if (w == 0) todo[0] = m & (m - 1); else if (w == 1) todo[1] = m & (m - 1); else todo[2] = m & (m - 1);
+            }
+        }
+
+        // utils.py:84-92
+        const int gy = cell / gw, gx = cell - gy * gw;
+        const float bx = (sigmoidf_(tl[0]) + (float)gx) * a.d.stride_x[l];
+        const float by = (sigmoidf_(tl[1]) + (float)gy) * a.d.stride_y[l];
+        const float bw = expf(tl[2]) * a.d.anchors[l][an < 3 ? an : 0][0];
+        const float bh = expf(tl[3]) * a.d.anchors[l][an < 3 ? an : 0][1];
+        const float conf = sigmoidf_(tl[4]);
+        // utils.py:118-126
+        const float hw = bw / 2.0f, hh = bh / 2.0f;
+        const float ymin = ((by - hh) - off_h / 2.0f) / scale;
+        const float xmin = ((bx - hw) - off_w / 2.0f) / scale;
+        const float ymax = ((by + hh) - off_h / 2.0f) / scale;
+        const float xmax = ((bx + hw) - off_w / 2.0f) / scale;
+        const float score = conf * (pmax * 1.0f);                                      // utils.py:153-154
+
+        const int p = a.scale_base[l] + cell * A + an;
+        if (live) {
+            float *r = a.records + ((long)b * N + p) * 8;
+            *(f32x4 *)r = f32x4{ymin, xmin, ymax, xmax};
+            *(f32x4 *)(r + 4) = f32x4{score, __uint_as_float(m0), __uint_as_float(m1), __uint_as_float(m2)};
+        }
+        const bool hit = live && score >= thr;                                         // inference.py:127
+        const unsigned long long hb = __builtin_amdgcn_ballot_w64(hit);
+        if (hb) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_n, __popcll(hb));
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (hit) {
+                s_list[wbase + __popcll(hb & ((1ull << lane) - 1ull))] = p;
+                unsigned mm[3] = {m0, m1, m2};
+                for (int w = 0; w < 3; ++w)
+                    while (mm[w]) { const int bit = __ffs(mm[w]) - 1; mm[w] &= mm[w] - 1; atomicAdd(&s_hist[w * 32 + bit], 1); }
+            }
+        }
+        // flush the block's candidate list before it could overflow (block-uniform decision needs a barrier, so
+        // the list is sized for every group this block will ever take: see the launch)
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (tid == 0) s_base = n ? atomicAdd(&a.cand_count[b], n) : 0;
+    if (tid < C && s_hist[tid]) atomicAdd(&a.class_count[b * C + tid], s_hist[tid]);
+    __syncthreads();
+    const int base = s_base;
+    for (int i = tid; i < n; i += kThreads) a.cand_idx[(long)b * N + base + i] = s_list[i];
+}
+
 // Dense forms (API parity with the reference helpers; not on the fused hot path).
 __global__ __launch_bounds__(kThreads) void get_head_kernel(const float *head, long total, int gh, int gw, int ld, int A,
                                                             int C, const float *anchors, float sx, float sy,
@@ -253,9 +433,34 @@ extern "C" int y3_decode(const y3_decode_desc *d, const float *head0, const floa
     a.scale_base[3] = base;
     Y3_REQUIRE(base == d->boxes_per_image, Y3_E_INVALID, "decode: boxes_per_image %d, grids give %d", d->boxes_per_image, base);
     a.letterbox = letterbox; a.records = records; a.cand_idx = cand_idx; a.cand_count = cand_count; a.class_count = class_count;
+    // lane-per-box kernel: 3 anchors x 16 cells fit a wavefront, a cell fits one LDS-DMA instruction, 16-byte
+    // aligned cells; anything else takes the 16-lanes-per-box kernel
+    bool lane_ok = d->num_anchors == 3 && !g_decode_force_v1;
+    for (int l = 0; l < d->num_scales; ++l)
+        lane_ok = lane_ok && d->head_ld[l] <= 256 && d->head_ld[l] % 4 == 0 && aligned16(heads[l]);
+    if (lane_ok) {
+        DecodeArgs2 q;
+        q.a = a;
+        q.groups_per_image = 0;
+        for (int l = 0; l < 3; ++l) {
+            q.groups[l] = l < d->num_scales ? (d->grid_h[l] * d->grid_w[l] + kCellsPerWave - 1) / kCellsPerWave : 0;
+            q.groups_per_image += q.groups[l];
+        }
+        // every block takes at most 8 groups per wave: its LDS candidate list holds 4 * 48 * 8 entries
+        q.slices = (q.groups_per_image + 31) / 32;
+        dim3 grid((unsigned)q.slices, (unsigned)d->batch);
+        hipLaunchKernelGGL(decode_lane_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, q);
+        return y3_check_launch("decode");
+    }
     dim3 grid((unsigned)((base + kChunk - 1) / kChunk), (unsigned)d->batch);
     hipLaunchKernelGGL(decode_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
     return y3_check_launch("decode");
+}
+
+// Test knob (not part of the stable contract): 1 = always the 16-lanes-per-box kernel, 0 = automatic.
+extern "C" int y3_decode_variant(int v) {
+    g_decode_force_v1 = v == 1;
+    return Y3_OK;
 }
 
 extern "C" int y3_get_head(const float *head, int batch, int grid_h, int grid_w, int head_ld, int num_anchors,
