@@ -187,6 +187,12 @@ int y3_pack_outputs(const float *records, const int32_t *kept_idx, const int32_t
                     int boxes_per_image, int num_classes, int max_boxes, float *out_boxes,
                     float *out_scores, int32_t *out_classes, int32_t *out_count, void *stream);
 
+/* Letterbox pre-process on the device: resize_image (utils/utils.py:7-40: aspect-preserving INTER_CUBIC
+ * resize to (int(w*scale), int(h*scale)), centre pad with 128) + the /255. of inference.py:242.
+ * image: uint8 RGB [h][w][3] on the device, rows row_stride_bytes apart; out: fp32 [in_h][in_w][3]. */
+int y3_letterbox_u8(const uint8_t *image, int h, int w, int row_stride_bytes, float *out, int in_h, int in_w,
+                    void *stream);
+
 /* Network input staging: fp32 [pixels][cin] (cin <= 8 bf16 / 4 fp32) -> dtype [pixels][one 16-byte chunk],
  * zero padded, so that the first convolution (cin = 3, build_model.py:86) runs on the MFMA kernel. */
 int y3_pad_input(int dtype, const float *in, void *out, int64_t pixels, int cin, void *stream);

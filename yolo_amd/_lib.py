@@ -53,6 +53,7 @@ SIGNATURES = {
     "y3_nms_workspace_ints": (c_i64, [c_int, c_int]),
     "y3_nms_lds_bytes": (c_int, [c_int]),
     "y3_pack_outputs": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_letterbox_u8": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "y3_pad_input": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
     "y3_cast_f32_to_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "y3_cast_bf16_to_f32": (c_int, [c_vp, c_vp, c_i64, c_vp]),

@@ -22,7 +22,7 @@ import torch
 from . import config
 from .build_model import load_weights, yolo
 from .postprocess import PostProcessor
-from .utils.utils import resize_image
+from .utils.utils import letterbox_gpu, resize_image  # noqa: F401  (resize_image: reference API, host path)
 
 parser = argparse.ArgumentParser(description="Run inference using darknet converted model")
 parser.add_argument("img_path", help="Path for running inference on a single image or multiple images")
@@ -143,11 +143,11 @@ def run_inference(img_path, output_dir, args):
     total_time_pred = []
     results = []
     for x, image in enumerate(images_batch):
-        image_data = np.array(resize_image(image, input_shape))
         print("Image height: {}\tImage width: {}".format(image.shape[0], image.shape[1]))
-        img = np.expand_dims(image_data / 255., 0).astype(np.float32)
+        # resize_image + /255. (inference.py:238-243) on the device: same pixels as the host path
+        img = letterbox_gpu(image, input_shape).unsqueeze(0)
         tick = time()
-        heads = output_nodes(torch.from_numpy(img))
+        heads = output_nodes(img)
         out_boxes, out_scores, out_classes = predict(heads, anchors, num_classes, input_shape,
                                                      [image.shape[0], image.shape[1]])
         out_boxes, out_scores, out_classes = (t.cpu().numpy() for t in (out_boxes, out_scores, out_classes))

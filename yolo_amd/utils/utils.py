@@ -64,6 +64,31 @@ def resize_image(image_data, size):
     return out
 
 
+def letterbox_gpu(image, size, out=None):
+    """Device form of `resize_image(image, size) / 255.` (utils/utils.py:7-40 + inference.py:242): uint8 RGB
+    [h,w,3] (numpy, or a torch tensor already on the GPU) -> fp32 cuda tensor [size_h,size_w,3], written
+    into `out` if given (e.g. one image slot of a batch tensor).  Same pixels as the host path."""
+    lib = _lib.load()
+    if not isinstance(image, torch.Tensor):
+        image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8))
+    if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
+        raise ValueError("letterbox_gpu: expected a uint8 [h,w,3] image, got %s %r" % (image.dtype, tuple(image.shape)))
+    if not image.is_cuda:
+        image = image.cuda()
+    if image.stride(2) != 1 or image.stride(1) != 3:
+        image = image.contiguous()
+    h, w = int(image.shape[0]), int(image.shape[1])
+    in_h, in_w = int(size[0]), int(size[1])
+    if out is None:
+        out = torch.empty((in_h, in_w, 3), dtype=torch.float32, device=image.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (in_h, in_w, 3) or not out.is_contiguous():
+        raise ValueError("letterbox_gpu: out must be a contiguous fp32 [%d,%d,3] tensor" % (in_h, in_w))
+    _lib.check(lib.y3_letterbox_u8(image.data_ptr(), h, w, int(image.stride(0)), out.data_ptr(), in_h, in_w,
+                                   _stream(image.device)))
+    out._y3_keep = image              # the source must outlive the asynchronous launch
+    return out
+
+
 def get_head(output, anchors, num_classes, input_shape, calc_loss=False):
     """-> box_xy [B,gh,gw,A,2], box_wh [B,gh,gw,A,2], box_confidence [B,gh,gw,A,1],
     box_class_probs [B,gh,gw,A,C] (reference utils/utils.py:43-96)."""
