@@ -191,3 +191,58 @@ def test_direct_first_layer_equals_padded_mfma_first_layer(dtype):
         for h, r in zip(net(torch.from_numpy(x)), ref):
             err = np.abs(h.cpu().numpy() - r).max()
             assert err <= 1e-3 if dtype == "fp32" else err / np.abs(r).max() <= 2e-2
+
+
+def test_run_inference_image_dir_contract(tmp_path):
+    """inference.py:170-331 end to end: a directory of images -> labels/<stem>.txt + images/<name>, through the
+    GPU letterbox, the network, decode and NMS; checked against the oracle run on the same files (fp32 mode:
+    coordinates may move by one pixel where floor(v + 0.5) sits on a boundary, scores within 2e-3)."""
+    import argparse
+    from PIL import Image
+    from oracle import letterbox as olb
+    rng = np.random.default_rng(5)
+    img_dir, out_dir = tmp_path / "imgs", tmp_path / "out"
+    img_dir.mkdir()
+    shapes = [(120, 160), (200, 150), (96, 96)]
+    for i, hw in enumerate(shapes):
+        Image.fromarray(rng.integers(0, 256, hw + (3,), dtype=np.uint8), mode="RGB").save(str(img_dir / ("im%d.png" % i)))
+    cfg = config.yolov3_tiny_cfg_path
+    layers, oi = od.parse_layers(cfg, 80)
+    params = dw.random_params(layers, seed=3)
+    wpath = str(tmp_path / "tiny.weights")
+    from yolo_amd import planner
+    dw.write_weights(wpath, planner.parse_cfg(cfg, 80)[0], params)
+    args = argparse.Namespace(cfg=cfg, weights=wpath, input_shape=416, dtype="fp32", darknet_model="1")
+    results = inference.run_inference(str(img_dir), str(out_dir), args)
+    anchors = inference.read_anchors(config.tiny_anchors_path)
+    assert sorted(os.listdir(str(out_dir / "images"))) == ["im0.png", "im1.png", "im2.png"]
+    found = 0
+    for i, hw in enumerate(shapes):
+        img = np.asarray(Image.open(str(img_dir / ("im%d.png" % i))).convert("RGB"))
+        x = olb.network_input(img, (416, 416))
+        heads = od.forward(layers, oi, params, x)
+        ob, os_, oc = odec.predict(heads, anchors, 80, (416, 416), hw, config.score_threshold, config.nms_threshold,
+                                   config.max_boxes)
+        want = odec.label_lines(ob, os_, oc, hw)
+        got = open(str(out_dir / "labels" / ("im%d.txt" % i))).read().splitlines()
+        assert len(got) == len(want) == len(results[i][2])
+        for g, w in zip(got, want):
+            gv, wv = g.split(","), w.split(",")
+            assert gv[4] == wv[4]
+            assert all(abs(int(a) - int(b)) <= 1 for a, b in zip(gv[:4], wv[:4]))
+            assert abs(float(gv[5]) - float(wv[5])) <= 2e-3
+        found += len(got)
+    assert found > 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_yolov3_spp_heads(dtype):
+    """cfg stem 'yolov3-spp': max-pool 5/9/13 stride 1 + four-way zero-copy concat, against the oracle."""
+    nodes, layers, oi, params = _net(config.yolov3_spp_cfg_path, dtype, 9)
+    x = np.random.default_rng(9).random((2, 160, 160, 3), dtype=np.float32)
+    heads = nodes(torch.from_numpy(x))
+    torch.cuda.synchronize()
+    ref = od.forward(layers, oi, params, x)
+    for h, r in zip(heads, ref):
+        err = np.abs(h.cpu().numpy() - r).max()
+        assert err <= (1e-3 if dtype == "fp32" else 2e-2 * np.abs(r).max())

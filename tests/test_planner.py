@@ -86,6 +86,20 @@ def test_stem_fusion_plan():
     assert planner.build_plan(tl, toi, 1, 416, 416, "bf16").ops[0]["kind"] == "conv"
 
 
+def test_yolov3_spp_plan_matches_oracle():
+    """cfg stem 'yolov3-spp' (build_model.py:70-71: head convolutions 59, 67, 75): max-pool 5/9/13 stride 1
+    SAME and a four-way route.  The three pools and the conv in front of them write straight into their
+    slices of the 2048-channel concat buffer; Darknet prints 141.45 BFLOPs for this cfg at 608."""
+    layers, oi = planner.parse_cfg(config.yolov3_spp_cfg_path, 80)
+    assert [L["conv_idx"] for L in layers if L["type"] == "conv" and L["head"]] == [59, 67, 75]
+    assert abs(planner.conv_gflops(layers, 608, 608) - 141.449) < 1e-3
+    plan = _check(config.yolov3_spp_cfg_path, 64, 1, True)
+    kinds = [op["kind"] for op in plan.ops]
+    assert kinds.count("maxpool") == 3 and kinds.count("conv") == 76 and "copy" not in kinds
+    pools = [op for op in plan.ops if op["kind"] == "maxpool"]
+    assert sorted(op["size"] for op in pools) == [5, 9, 13] and all(op["y"]["ld"] == 2048 for op in pools)
+
+
 def test_layer_walk_quirks():
     layers, oi = planner.parse_cfg(config.yolov3_tiny_cfg_path, 80)
     assert oi == [15, 22] and len(layers) == 24

@@ -23,6 +23,7 @@ anchors_path = os.path.join(_HERE, "model_data", "yolo_anchors_pre-trained.txt")
 tiny_anchors_path = os.path.join(_HERE, "model_data", "yolo_tiny_anchors.txt")   # from yolov3-tiny.cfg:134
 yolov3_cfg_path = os.path.join(_HERE, "darknet_data", "yolov3.cfg")            # config.py:45
 yolov3_tiny_cfg_path = os.path.join(_HERE, "darknet_data", "yolov3-tiny.cfg")
+yolov3_spp_cfg_path = os.path.join(_HERE, "darknet_data", "yolov3-spp.cfg")   # stem 'yolov3-spp' (build_model.py:70-71); cfg generated here, the reference ships none
 yolov3_weights_path = os.path.join(_HERE, "darknet_data", "yolov3.weights")    # config.py:46
 classes_path = os.path.join(_HERE, "model_data", "coco_classes.txt")           # config.py:49
 

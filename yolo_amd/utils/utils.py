@@ -70,7 +70,7 @@ def letterbox_gpu(image, size, out=None):
     into `out` if given (e.g. one image slot of a batch tensor).  Same pixels as the host path."""
     lib = _lib.load()
     if not isinstance(image, torch.Tensor):
-        image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8))
+        image = torch.from_numpy(np.array(image, dtype=np.uint8))       # a copy: PIL arrays are read-only
     if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
         raise ValueError("letterbox_gpu: expected a uint8 [h,w,3] image, got %s %r" % (image.dtype, tuple(image.shape)))
     if not image.is_cuda:
