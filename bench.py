@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=0, help="sub-batch the plan runs at a time (0 = whole batch)")
     ap.add_argument("--score-threshold", type=float, default=config.score_threshold)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=4, help="timed images of the CPU baseline (plus 1 warm-up)")
+    ap.add_argument("--cpu-images", type=int, default=24, help="timed images of the CPU baseline (plus 1 warm-up)")
     ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
 

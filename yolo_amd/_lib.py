@@ -71,6 +71,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "or `make -C yolo_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        # torch first: it brings its own HIP runtime (libamdhip64), and the library must bind to that one.
+        # Loaded before torch, libyolo3hip.so pulls the system runtime in and every launch then fails with
+        # "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

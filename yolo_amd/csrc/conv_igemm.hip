@@ -731,7 +731,7 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
             tile = (c256 <= c192 && c256 <= c128) ? 256 : (c192 <= c128 ? 192 : 128);
         }
     }
-    if (tile >= 192 && tile != 257 && d->n_pad % 256 != 0) tile = 128;
+    if ((tile >= 192 || tile == 129) && tile != 257 && d->n_pad % 256 != 0) tile = 128;
     return tile;
 }
 
@@ -867,6 +867,7 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     if (bf16) {
         if (v == 257) return launch_ring<true, 256, 128, 2, 2, 128, 3>(a, d->n_pad, stream);
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
+        if (v == 129) return launch_igemm<true, 128, 256, 2, 4, 64>(a, d->n_pad, stream);     // experiment
         if (v == 192) return launch_igemm<true, 192, 256, 2, 4, 96>(a, d->n_pad, stream);
         if (v == 128) return launch_igemm<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
         if (v == 64) return launch_igemm<true, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
@@ -895,6 +896,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     const int v = conv_variant(d, M);
     const char *k = (g_conv_debug & 4) && v >= 128 ? "conv_igemm_ring_kernel" : "conv_igemm_kernel";
     if (v == 257) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 128, 2, 2", t);
+    else if (v == 129) snprintf(buf, (size_t)len, "%s<%s, 128, 256, 2, 4", k, t);
     else if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
     else if (v == 192) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
     else if (v == 128) snprintf(buf, (size_t)len, "%s<%s, 128, 128, 2, 2", k, t);
@@ -907,7 +909,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
-    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 192 || tile == 256 || tile == 257, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
+    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 129 || tile == 192 || tile == 256 || tile == 257, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
     g_conv_tile = tile;
     return Y3_OK;
 }
