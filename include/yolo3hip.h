@@ -97,6 +97,8 @@ int y3_conv_kernel_name(const y3_conv_desc *desc, char *buf, int len);
 
 /* Tuning knob for experiments: force the implicit-GEMM tile (0 = heuristic, 128, 256). Process-global. */
 int y3_set_conv_tile(int tile);
+/* Tuning knob: start offset of the de-phased persistent workgroups in percent of a tile period (default 50, 0 = off). */
+int y3_set_conv_phase(int percent);
 
 /* tf.nn.max_pool(padding='SAME'), build_model.py:207-210.  c % (16/elsize) == 0. */
 int y3_maxpool2d(int dtype, const void *in, void *out, int batch, int in_h, int in_w, int c,

@@ -26,6 +26,7 @@ namespace {
 
 int g_conv_tile = 0;      // experiment knobs, see y3_set_conv_tile
 int g_conv_debug = 0;
+int g_conv_phase_pct = 50;          // start offset of the de-phased workgroups, percent of a tile period (0 = off)
 
 struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
 
@@ -43,6 +44,8 @@ struct ConvArgs {
     FastDiv fd_howo, fd_wo;
     unsigned out_bytes, res_bytes;     // extents for the buffer descriptors of the register epilogue
     int total_tiles;
+    int delay_from;                    // persistent workgroups with blockIdx.x >= delay_from start delay_ticks late
+    unsigned delay_ticks;              // in s_memrealtime ticks (100 MHz)
 };
 
 // Output row gm -> byte offset of its window's first input element and the 9-bit (1-bit for 1x1)
@@ -293,6 +296,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     // Workgroups are persistent when the grid is smaller than the tile count: tile = blockIdx.x, + gridDim.x, ...
     // (gridDim.x is then a multiple of 8, so a workgroup's tiles keep its XCD).  The next tile's set-up and
     // first loads overlap the previous tile's stores, which nothing waits for.
+    // De-phasing.  Equal tiles keep every workgroup in lockstep: all of them reach the HBM-bound epilogue
+    // together, the chip waits for HBM, then HBM idles through the next main loop.  The workgroups that have a
+    // spare round (see the launcher) therefore start half a tile period late, so that their epilogues fall
+    // into the others' main loops and the bursts are smaller.
+    if (p.delay_ticks != 0u && (int)blockIdx.x >= p.delay_from) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < p.delay_ticks) __builtin_amdgcn_s_sleep(64);
+    }
     int pb = 0;                                  // pipeline buffer the next k-step reads
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
     const int bid = xcd_remap(tile, p.total_tiles);
@@ -673,6 +684,18 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
     // persistent grid: as many workgroups as stay resident (LDS-limited), each walking several tiles
     const long resident = 256L * (lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3));
     const long grid = (g_conv_debug & 128) || nblk <= resident ? nblk : resident;
+    a.delay_ticks = 0;
+    a.delay_from = 0;
+    // De-phase only where it is free and measured to pay: one workgroup per CU (the 256- and 192-row tiles),
+    // several rounds, and a last round that is not full -- the workgroups with one tile fewer to do start half
+    // a tile period late (76x76 3x3 layers: -6 %).  Delaying workgroups that have no spare round, or one of a
+    // CU's two co-resident workgroups of the 128-row tiles, measured neutral to slightly slower.
+    const long rem = nblk % grid;
+    if (grid == resident && resident == 256 && nblk >= 4 * resident && rem != 0 && g_conv_phase_pct > 0) {
+        const double tile_us = 2.0 * BM * BN * (double)a.Kpad / (BF16 ? 4.8e6 : 0.3e6);      // at ~4.8 TFLOP/s per CU
+        a.delay_ticks = (unsigned)(tile_us * g_conv_phase_pct);                              // 100 ticks per us, percent
+        a.delay_from = (int)rem;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, stream, a);
     return y3_check_launch("conv_igemm");
 }
@@ -906,6 +929,13 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
 }
 
 // Experiment knob (not part of the stable ABI contract): force the conv tile (0 = heuristic).
+// Experiment knob: start offset of the de-phased persistent workgroups, percent of a tile period (0 = off).
+extern "C" int y3_set_conv_phase(int percent) {
+    Y3_REQUIRE(percent >= 0 && percent <= 400, Y3_E_INVALID, "conv phase %d%% (0..400)", percent);
+    g_conv_phase_pct = percent;
+    return Y3_OK;
+}
+
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
