@@ -99,6 +99,8 @@ int y3_conv_kernel_name(const y3_conv_desc *desc, char *buf, int len);
 int y3_set_conv_tile(int tile);
 /* Tuning knob: start offset of the de-phased persistent workgroups in percent of a tile period (default 50, 0 = off). */
 int y3_set_conv_phase(int percent);
+/* Tuning knob: CUs one convolution launch may occupy (default 256; two streams with 128 each overlap two layers). */
+int y3_set_conv_cus(int cus);
 
 /* tf.nn.max_pool(padding='SAME'), build_model.py:207-210.  c % (16/elsize) == 0. */
 int y3_maxpool2d(int dtype, const void *in, void *out, int batch, int in_h, int in_w, int c,

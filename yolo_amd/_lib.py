@@ -39,6 +39,7 @@ SIGNATURES = {
     "y3_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_int]),
     "y3_set_conv_tile": (c_int, [c_int]),
     "y3_set_conv_phase": (c_int, [c_int]),
+    "y3_set_conv_cus": (c_int, [c_int]),
     "y3_maxpool2d": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "y3_upsample2x": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "y3_copy_channels": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),

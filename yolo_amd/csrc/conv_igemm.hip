@@ -26,6 +26,7 @@ namespace {
 
 int g_conv_tile = 0;      // experiment knobs, see y3_set_conv_tile
 int g_conv_debug = 0;
+int g_conv_cus = 256;               // CUs a launch may occupy (experiment knob: y3_set_conv_cus)
 int g_conv_phase_pct = 50;          // start offset of the de-phased workgroups, percent of a tile period (0 = off)
 
 struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
@@ -528,11 +529,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_ring_kernel
         }
     };
 
+    const bool reg_epi = BF16 && (p.flags & CONV_REG_EPILOGUE);     // then the bias is the accumulators' initial value
     f32x4 acc[NI][MI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int ni = 0; ni < NI; ++ni) {
+        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (reg_epi) b0 = *(const f32x4 *)(p.bias + n0 + wn * TN + ni * 16 + (lane >> 4) * 4);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = b0;
+    }
 
     const int frow = lane & 15;
     const int fq = lane >> 4;
@@ -592,6 +597,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_ring_kernel
         }
         rd = rd + 1 == RING ? 0 : rd + 1;
         wr = wr + 1 == RING ? 0 : wr + 1;
+    }
+    if constexpr (BF16) {
+        if (reg_epi) {
+            conv_epilogue_regs<TM, TN, MI, NI>(p, acc, m0, n0, lane, wm, wn);
+            return;
+        }
     }
     conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI>(p, acc, smem, m0, n0, tid, wm, wn);
 }
@@ -682,7 +693,7 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv: grid of %ld blocks", nblk); return Y3_E_INVALID; }
     a.total_tiles = (int)nblk;
     // persistent grid: as many workgroups as stay resident (LDS-limited), each walking several tiles
-    const long resident = 256L * (lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3));
+    const long resident = (long)g_conv_cus * (lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3));
     const long grid = (g_conv_debug & 128) || nblk <= resident ? nblk : resident;
     a.delay_ticks = 0;
     a.delay_from = 0;
@@ -691,7 +702,7 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
     // a tile period late (76x76 3x3 layers: -6 %).  Delaying workgroups that have no spare round, or one of a
     // CU's two co-resident workgroups of the 128-row tiles, measured neutral to slightly slower.
     const long rem = nblk % grid;
-    if (grid == resident && resident == 256 && nblk >= 4 * resident && rem != 0 && g_conv_phase_pct > 0) {
+    if (grid == resident && resident == g_conv_cus && nblk >= 4 * resident && rem != 0 && g_conv_phase_pct > 0) {
         const double tile_us = 2.0 * BM * BN * (double)a.Kpad / (BF16 ? 4.8e6 : 0.3e6);      // at ~4.8 TFLOP/s per CU
         a.delay_ticks = (unsigned)(tile_us * g_conv_phase_pct);                              // 100 ticks per us, percent
         a.delay_from = (int)rem;
@@ -723,7 +734,10 @@ int launch_ring(ConvArgs a, int n_pad, hipStream_t stream) {
     const long nblk = (long)m_tiles * a.n_tiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv: grid of %ld blocks", nblk); return Y3_E_INVALID; }
     a.total_tiles = (int)nblk;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, stream, a);
+    a.delay_ticks = 0; a.delay_from = 0;
+    // with the register epilogue the LDS staging area of the other epilogue is not needed: more workgroups per CU
+    const int lds_used = (a.flags & CONV_REG_EPILOGUE) ? ring_bytes : lds;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds_used, stream, a);
     return y3_check_launch("conv_igemm_ring");
 }
 
@@ -891,6 +905,8 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
         if (v == 257) return launch_ring<true, 256, 128, 2, 2, 128, 3>(a, d->n_pad, stream);
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
         if (v == 129) return launch_igemm<true, 128, 256, 2, 4, 64>(a, d->n_pad, stream);     // experiment
+        if (v == 130) return launch_ring<true, 128, 128, 2, 2, 128, 3>(a, d->n_pad, stream);   // 48 KB: 3 per CU
+        if (v == 131) return launch_ring<true, 128, 128, 2, 2, 128, 4>(a, d->n_pad, stream);   // 64 KB: 2 per CU, 3 sub-steps ahead
         if (v == 192) return launch_igemm<true, 192, 256, 2, 4, 96>(a, d->n_pad, stream);
         if (v == 128) return launch_igemm<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
         if (v == 64) return launch_igemm<true, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
@@ -920,6 +936,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     const char *k = (g_conv_debug & 4) && v >= 128 ? "conv_igemm_ring_kernel" : "conv_igemm_kernel";
     if (v == 257) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 128, 2, 2", t);
     else if (v == 129) snprintf(buf, (size_t)len, "%s<%s, 128, 256, 2, 4", k, t);
+    else if (v == 130 || v == 131) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 128, 128, 2, 2", t);
     else if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
     else if (v == 192) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
     else if (v == 128) snprintf(buf, (size_t)len, "%s<%s, 128, 128, 2, 2", k, t);
@@ -929,6 +946,14 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
 }
 
 // Experiment knob (not part of the stable ABI contract): force the conv tile (0 = heuristic).
+// Experiment knob: how many CUs one convolution launch may occupy (persistent grid size); two streams with
+// 128 each run two layers side by side.
+extern "C" int y3_set_conv_cus(int cus) {
+    Y3_REQUIRE(cus >= 8 && cus <= 256 && cus % 8 == 0, Y3_E_INVALID, "conv CUs %d (8..256, multiple of 8)", cus);
+    g_conv_cus = cus;
+    return Y3_OK;
+}
+
 // Experiment knob: start offset of the de-phased persistent workgroups, percent of a tile period (0 = off).
 extern "C" int y3_set_conv_phase(int percent) {
     Y3_REQUIRE(percent >= 0 && percent <= 400, Y3_E_INVALID, "conv phase %d%% (0..400)", percent);
@@ -939,7 +964,7 @@ extern "C" int y3_set_conv_phase(int percent) {
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
-    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 129 || tile == 192 || tile == 256 || tile == 257, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
+    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 257, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
     g_conv_tile = tile;
     return Y3_OK;
 }
