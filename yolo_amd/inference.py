@@ -9,8 +9,9 @@ inference.py, same public names and argument order:
     CLI:  python -m yolo_amd.inference <img_dir> <out_dir> [--darknet_model 1]   inference.py:20-24
 
 predict() takes evaluated head tensors (what `sess.run(output_nodes)` would give) and runs
-the fused decode + per-class NMS kernels.  Drawing (inference.py:284-325) is reduced to the
-label-file contract; PIL is used for image decode in place of cv2 (absent here).
+the fused decode + per-class NMS kernels.  Drawing (inference.py:284-325) follows the reference (class
+colours, outline thickness, label placement) with whatever TrueType font PIL finds, since the reference's
+font file is not shipped; PIL is used for image decode in place of cv2 (absent here).
 """
 import argparse
 import os
@@ -116,9 +117,65 @@ def label_lines(out_boxes, out_scores, out_classes, image_hw):
     return lines
 
 
+def class_colors(num):
+    """One RGB colour per class, as inference.py:209-215: evenly spaced hues, shuffled with the fixed seed
+    10101 so that adjacent classes differ and runs agree."""
+    import colorsys
+    import random
+    colors = [colorsys.hsv_to_rgb(x / num, 1., 1.) for x in range(num)]
+    colors = [(int(r * 255), int(g * 255), int(b * 255)) for r, g, b in colors]
+    rnd = random.Random(10101)              # the reference seeds the global generator and resets it afterwards
+    rnd.shuffle(colors)
+    return colors
+
+
+def _label_font(image_width):
+    """The reference loads ./font/FiraMono-Medium.otf at size floor(0.01*w + 0.5) (inference.py:285-286); that
+    file is not shipped here, so any TrueType font PIL can find is used at that size, else PIL's built-in."""
+    from PIL import ImageFont
+    size = max(int(np.floor(1e-2 * image_width + 0.5)), 8)
+    for name in (getattr(config, "font_path", None), "DejaVuSansMono.ttf", "DejaVuSans.ttf"):
+        if not name:
+            continue
+        try:
+            return ImageFont.truetype(name, size=size)
+        except (OSError, ValueError):
+            continue
+    return ImageFont.load_default()
+
+
+def draw_detections(image, out_boxes, out_scores, out_classes, class_names, colors=None):
+    """Annotated copy of `image` (uint8 RGB array) as inference.py:284-321 draws it: per detection, in reverse
+    order, a box outline (h+w)//500 pixels thick in the class colour and a filled label `name score` above
+    the box (inside it when there is no room).  Returns a PIL image."""
+    from PIL import Image, ImageDraw
+    colors = colors or class_colors(len(class_names))
+    h, w = image.shape[:2]
+    font = _label_font(w)
+    thickness = (h + w) // 500
+    img = Image.fromarray(np.asarray(image).astype("uint8"), mode="RGB")
+    draw = ImageDraw.Draw(img)
+    for i, c in reversed(list(enumerate(out_classes))):
+        label = "{} {:.4f}".format(class_names[c], out_scores[i])
+        x0, y0, x1, y1 = draw.textbbox((0, 0), label, font=font)
+        label_size = np.array([x1 - x0, y1 - y0])
+        top, left, bottom, right = out_boxes[i]
+        top = max(0, int(np.floor(top + 0.5)))
+        left = max(0, int(np.floor(left + 0.5)))
+        bottom = min(h, int(np.floor(bottom + 0.5)))
+        right = min(w, int(np.floor(right + 0.5)))
+        origin = np.array([left, top - label_size[1]]) if top - label_size[1] >= 0 else np.array([left, top + 1])
+        for j in range(thickness):
+            if right - j >= left + j and bottom - j >= top + j:
+                draw.rectangle([left + j, top + j, right - j, bottom - j], outline=colors[c])
+        draw.rectangle([tuple(origin), tuple(origin + label_size)], fill=colors[c])
+        draw.text(tuple(origin), label, fill=(0, 0, 0), font=font)
+    return img
+
+
 def run_inference(img_path, output_dir, args):
-    """inference.py:170-331: every image of img_path -> output_dir/labels/<stem>.txt (+ a copy of
-    the image under output_dir/images), one image per step, FPS excluding the first image."""
+    """inference.py:170-331: every image of img_path -> output_dir/labels/<stem>.txt and the annotated image
+    under output_dir/images, one image per step, FPS excluding the first image."""
     for d in (output_dir, os.path.join(output_dir, "images"), os.path.join(output_dir, "labels")):
         if not os.path.exists(d):
             os.mkdir(d)
@@ -140,6 +197,7 @@ def run_inference(img_path, output_dir, args):
                                   "branch of the reference (inference.py:258-266) is out of scope")
     load_weights(output_nodes, weights)      # FileNotFoundError if absent: nothing is downloaded
 
+    colors = class_colors(len(class_names))
     total_time_pred = []
     results = []
     for x, image in enumerate(images_batch):
@@ -159,8 +217,8 @@ def run_inference(img_path, output_dir, args):
             print("{} {:.4f}".format(class_names[c], out_scores[i]))
         with open(os.path.join(output_dir, "labels", file_names[x].split(".")[0] + ".txt"), "w") as fh:
             fh.write("".join(l + "\n" for l in lines))
-        from PIL import Image
-        Image.fromarray(image.astype("uint8"), mode="RGB").save(os.path.join(output_dir, "images", file_names[x]))
+        draw_detections(image, out_boxes, out_scores, out_classes, class_names, colors).save(
+            os.path.join(output_dir, "images", file_names[x]), compress_level=1)
         results.append((out_boxes, out_scores, out_classes))
     if len(images_batch) > 1:
         t = sum(total_time_pred[1:])
