@@ -232,7 +232,30 @@ def test_run_inference_image_dir_contract(tmp_path):
             assert all(abs(int(a) - int(b)) <= 1 for a, b in zip(gv[:4], wv[:4]))
             assert abs(float(gv[5]) - float(wv[5])) <= 2e-3
         found += len(got)
+        drawn = np.asarray(Image.open(str(out_dir / "images" / ("im%d.png" % i))).convert("RGB"))
+        assert drawn.shape == img.shape and (len(got) == 0) == bool((drawn == img).all())    # boxes are drawn (inference.py:314-321)
     assert found > 0
+
+
+@pytest.mark.gpu
+def test_frozen_graph_named_nodes():
+    """predict_from_pb.py:221-251 against the node-name shim: fetching scale_1..3 by name with input_image fed
+    returns exactly what the network's own call returns, and predict() on them gives the same detections."""
+    from yolo_amd import frozen_graph
+    from yolo_amd.build_model import Network
+    cfg = config.yolov3_cfg_path
+    net = Network(cfg, 80, dtype="fp32")
+    net.set_params(dw.random_params(od.parse_layers(cfg, 80)[0], seed=11))
+    x = np.random.default_rng(4).random((1, 96, 96, 3), dtype=np.float32)
+    g = frozen_graph.FrozenGraph(net)
+    nodes = [g.get_tensor_by_name("scale_%d:0" % k) for k in (1, 2, 3)]
+    got = [t.clone() for t in g.run(nodes, {g.get_tensor_by_name("input_image:0"): x, "input_shape:0": (96, 96)})]
+    want = net(torch.from_numpy(x))
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a[..., :255], b[..., :255])
+    assert [t.shape[1] for t in got] == [3, 6, 12]
+    one = g.run("scale_2:0", {"input_image:0": x[0]})              # [S,S,3] gets its batch dimension
+    assert torch.equal(one[..., :255], want[1][..., :255])
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -39,3 +39,23 @@ def test_draw_detections_outline_label_and_clipping():
     assert tuple(out[30, 250]) == cols[2]
     lines = inference.label_lines(boxes, np.array([0.9, 0.7], dtype=np.float32), np.array([1, 2]), (200, 300))
     assert lines[0].startswith("250,0,300,40,2,") and lines[1].startswith("60,50,201,121,1,")
+
+
+def test_frozen_graph_node_names():
+    """Terminal node names of the reference's frozen graph (convert_to_pb.py:11; predict_from_pb.py:221-225)."""
+    import pytest
+    from yolo_amd import frozen_graph
+    from yolo_amd.build_model import Network
+    assert frozen_graph.terminal_node_names == ["input_image", "input_shape", "scale_1", "scale_2", "scale_3"]
+    net = Network.__new__(Network)          # no device needed to look names up
+    net.out_index = [0, 1]                  # a two-head (tiny) network has no scale_3
+    g = frozen_graph.FrozenGraph(net)
+    assert g.get_tensor_by_name("scale_2:0").name == "scale_2"
+    assert g.get_tensor_by_name("input_image:0") == g.get_tensor_by_name("input_image")
+    with pytest.raises(KeyError):
+        g.get_tensor_by_name("scale_3:0")
+    with pytest.raises(KeyError):
+        g.get_tensor_by_name("scale_1:1")
+    with pytest.raises(ValueError):
+        g.run("scale_1:0", {})
+    assert list(g.run("input_shape:0", {"input_shape:0": (480, 640)})) == [480, 640]
