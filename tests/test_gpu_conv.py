@@ -189,7 +189,7 @@ def test_conv_tile256_equals_tile128(case, dtype):
     """Every tile variant against the oracle, and against each other: variants that share an epilogue
     sum each output in the same order -> identical bits.  Two epilogue families exist in bf16 mode:
     the register epilogue (bias is the accumulator's initial value) and the LDS epilogue (bias added
-    last; ring kernels, fp32 mode, and debug bit 64)."""
+    last; fp32 mode, and debug bit 64); the ring kernels (257, debug bit 4) have both as well."""
     from yolo_amd import _lib
     lib = _lib.load()
     B, H, C, O, ks, stride, leaky = case
@@ -201,8 +201,8 @@ def test_conv_tile256_equals_tile128(case, dtype):
     if dtype == "bf16":
         x, k, r = gpu_util.bf16_round(x), gpu_util.bf16_round(k), gpu_util.bf16_round(r)
     # low half: tile; high half: experiment bits (4 = ring-pipelined main loop, 2 = no interleave, 64 = LDS epilogue)
-    reg_family = (128, 192, 256, (2 << 16) | 256)
-    lds_family = ((64 << 16) | 128, (64 << 16) | 192, (64 << 16) | 256, 257, (4 << 16) | 128, (4 << 16) | 256)
+    reg_family = (128, 192, 256, (2 << 16) | 256, 257, (4 << 16) | 128, (4 << 16) | 256)
+    lds_family = ((64 << 16) | 128, (64 << 16) | 192, (64 << 16) | 256, (64 << 16) | 257, (68 << 16) | 128, (68 << 16) | 256)
     want = _ref(x, k, b, stride, leaky, residual=r)
     tol = 1e-3 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(want))
     outs = {}
