@@ -84,9 +84,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 path on a one-GPU box (YOLO_AMD_BENCH_REHEARSAL=1): every rank uses device 0 and the
+    # collectives run over gloo; the numbers mean nothing, the code path (barriers, max-over-ranks, gather) is real.
+    rehearsal = os.environ.get("YOLO_AMD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo3hip.so")
+LIB_PATH = os.environ.get("YOLO3HIP_LIB") or os.path.join(_HERE, "libyolo3hip.so")     # override: A/B builds
 
 Y3_F32, Y3_BF16 = 0, 1
 CONV_LEAKY, CONV_RESIDUAL, CONV_UPS2X, CONV_OUT_F32, CONV_IN_F32 = 1, 2, 4, 8, 16

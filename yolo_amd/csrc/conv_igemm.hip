@@ -202,32 +202,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
 // which the hardware ignores, so there is no branch around them.  All residual loads of the wave's tile are
 // issued before the first is used.
 constexpr int CONV_REG_EPILOGUE = 1 << 26;
+#ifndef Y3_RES_EARLY_16THS
+#define Y3_RES_EARLY_16THS 16
+#endif
 
-template <int TM, int TN, int MI, int NI>
-__device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&acc)[NI][MI], int m0, int n0, int lane, int wm, int wn) {
+// Residual pieces [FROM, TO) of the wave's tile (piece = mi * NI/2 + pair): one 16-byte buffer load each.
+// The main loop's last k-step issues the first RES_EARLY pieces (its loader registers are free by then), so
+// that they arrive under its MFMAs; the epilogue issues the rest.
+template <int TM, int TN, int MI, int NI, int FROM, int TO>
+__device__ __forceinline__ void conv_residual_load(const ConvArgs &p, u32x4 (&rv)[MI][NI / 2], int m0, int n0, int lane, int wm, int wn) {
+    constexpr int NP2 = NI / 2;
+    const int frow = lane & 15, fq = lane >> 4;
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, p.res_bytes, 0x00020000);
+    const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
+    const int nl = n0 + wn * TN + cb;
+    constexpr unsigned OOB = 0xffffff00u;
+#pragma unroll
+    for (int i = FROM; i < TO; ++i) {
+        const int mi = i / NP2, pr = i % NP2;
+        const int gm = m0 + wm * TM + mi * 16 + frow;
+        const bool ok = gm < p.M && nl + pr * 32 < p.Cout8;
+        rv[mi][pr] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs_res, ok ? ((unsigned)gm * (unsigned)p.res_ld + (unsigned)nl) * 2u : OOB, pr * 64, 0));
+    }
+}
+
+template <int TM, int TN, int MI, int NI, int RES_EARLY>
+__device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&acc)[NI][MI], u32x4 (&rv_early)[MI][NI / 2], int m0, int n0, int lane, int wm, int wn) {
     static_assert(NI % 2 == 0, "register epilogue pairs 16-channel blocks");
     constexpr int NP2 = NI / 2;
     const int frow = lane & 15, fq = lane >> 4;
     const bool has_res = p.flags & Y3_CONV_RESIDUAL;
     const float slope = (p.flags & Y3_CONV_LEAKY) ? 0.1f : 1.0f;
     const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
-    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? p.res : p.zeros), 0, has_res ? p.res_bytes : 0u, 0x00020000);
     const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
     const int nl = n0 + wn * TN + cb;                       // this lane's first channel in pair 0
     constexpr unsigned OOB = 0xffffff00u;
-    u32x4 rv[MI][NP2];
-    if (has_res) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int gm = m0 + wm * TM + mi * 16 + frow;
-#pragma unroll
-            for (int pr = 0; pr < NP2; ++pr) {
-                const bool ok = gm < p.M && nl + pr * 32 < p.Cout8;
-                rv[mi][pr] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rs_res, ok ? ((unsigned)gm * (unsigned)p.res_ld + (unsigned)nl) * 2u : OOB, pr * 64, 0));
-            }
-        }
-    }
+    u32x4 rv_own[MI][NP2];
+    u32x4 (&rv)[MI][NP2] = RES_EARLY > 0 ? rv_early : rv_own;   // a caller's array costs the 256x256 kernel 65 spilled registers
+    if (has_res) conv_residual_load<TM, TN, MI, NI, RES_EARLY, MI * NP2>(p, rv, m0, n0, lane, wm, wn);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int gm = m0 + wm * TM + mi * 16 + frow;
@@ -382,11 +395,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     const int fq = lane >> 4;
     const int nk = p.Kpad / BKE;
 
-    auto kstep = [&](int kt, auto prefetch) {
+    // residual pieces the last k-step fetches ahead of the epilogue (register epilogue only)
+    constexpr int RES_EARLY = (BF16 && NI % 2 == 0 && MI * NI * 4 <= 96) ? (MI * (NI / 2) * Y3_RES_EARLY_16THS) / 16 : 0;
+    auto kstep = [&](int kt, auto prefetch, auto early) {
         constexpr bool PF = decltype(prefetch)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of tile kt has landed
         __syncthreads();                                    // everyone's has; buffer (kt+1)&1 is free
         if constexpr (PF) stage_begin();
+        early();
         const char *As = smem + pb * STAGE;
         const char *Bs = As + BM * 128;
 #pragma unroll
@@ -430,8 +446,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     stage_begin();
 #pragma unroll
     for (int q = 0; q < NP; ++q) piece(q, 0, pb);       // free: every wave is past the barrier of the last k-step
-    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
-    kstep(nk - 1, std::false_type{});
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, [] {});
+    u32x4 rv[MI][NI % 2 == 0 ? NI / 2 : 1];
+    kstep(nk - 1, std::false_type{}, [&] {
+        if constexpr (RES_EARLY > 0) {
+            if (reg_epi && (p.flags & Y3_CONV_RESIDUAL)) {
+                conv_residual_load<TM, TN, MI, NI, 0, RES_EARLY>(p, rv, m0, n0, lane, wm, wn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    });
 
     if (p.flags & (1 << 27)) {          // timing experiment: no epilogue (one store keeps the accumulators live)
         float sacc = 0.f;
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     }
     if constexpr (BF16) {
         if (reg_epi) {
-            conv_epilogue_regs<TM, TN, MI, NI>(p, acc, m0, n0, lane, wm, wn);
+            conv_epilogue_regs<TM, TN, MI, NI, RES_EARLY>(p, acc, rv, m0, n0, lane, wm, wn);
             continue;
         }
     }
@@ -600,7 +624,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_ring_kernel
     }
     if constexpr (BF16) {
         if (reg_epi) {
-            conv_epilogue_regs<TM, TN, MI, NI>(p, acc, m0, n0, lane, wm, wn);
+            u32x4 rv[MI][NI / 2];
+            conv_epilogue_regs<TM, TN, MI, NI, 0>(p, acc, rv, m0, n0, lane, wm, wn);
             return;
         }
     }
@@ -768,7 +793,7 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
             tile = (c256 <= c192 && c256 <= c128) ? 256 : (c192 <= c128 ? 192 : 128);
         }
     }
-    if ((tile >= 192 || tile == 129) && tile != 257 && d->n_pad % 256 != 0) tile = 128;
+    if ((tile >= 192 || tile == 129) && tile != 257 && tile != 258 && d->n_pad % 256 != 0) tile = 128;
     return tile;
 }
 
@@ -905,6 +930,7 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
         if (v == 257) return launch_ring<true, 256, 128, 2, 2, 128, 3>(a, d->n_pad, stream);
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
         if (v == 129) return launch_igemm<true, 128, 256, 2, 4, 64>(a, d->n_pad, stream);     // experiment
+        if (v == 258) return launch_igemm<true, 256, 128, 4, 2, 128>(a, d->n_pad, stream);    // 256 pixels x 128 channels, 8 waves
         if (v == 130) return launch_ring<true, 128, 128, 2, 2, 128, 3>(a, d->n_pad, stream);   // 48 KB: 3 per CU
         if (v == 131) return launch_ring<true, 128, 128, 2, 2, 128, 4>(a, d->n_pad, stream);   // 64 KB: 2 per CU, 3 sub-steps ahead
         if (v == 192) return launch_igemm<true, 192, 256, 2, 4, 96>(a, d->n_pad, stream);
@@ -936,6 +962,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     const char *k = (g_conv_debug & 4) && v >= 128 ? "conv_igemm_ring_kernel" : "conv_igemm_kernel";
     if (v == 257) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 128, 2, 2", t);
     else if (v == 129) snprintf(buf, (size_t)len, "%s<%s, 128, 256, 2, 4", k, t);
+    else if (v == 258) snprintf(buf, (size_t)len, "conv_igemm_kernel<%s, 256, 128, 4, 2", t);
     else if (v == 130 || v == 131) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 128, 128, 2, 2", t);
     else if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
     else if (v == 192) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
@@ -964,7 +991,7 @@ extern "C" int y3_set_conv_phase(int percent) {
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
-    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 257, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
+    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 257 || tile == 258, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
     g_conv_tile = tile;
     return Y3_OK;
 }
