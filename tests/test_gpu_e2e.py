@@ -269,3 +269,61 @@ def test_yolov3_spp_heads(dtype):
     for h, r in zip(heads, ref):
         err = np.abs(h.cpu().numpy() - r).max()
         assert err <= (1e-3 if dtype == "fp32" else 2e-2 * np.abs(r).max())
+
+
+def _synthetic_heads(rng, B, grids, obj_mean):
+    heads = []
+    for g in grids:
+        t = np.empty((B, g, g, 3, 85), dtype=np.float32)
+        t[..., 0:2] = rng.standard_normal((B, g, g, 3, 2))
+        t[..., 2:4] = rng.standard_normal((B, g, g, 3, 2)) * 0.5
+        t[..., 4] = rng.standard_normal((B, g, g, 3)) * 2 + obj_mean
+        t[..., 5:] = rng.standard_normal((B, g, g, 3, 80)) * 2 - 2
+        heads.append(t.reshape(B, g, g, 255))
+    return heads
+
+
+def test_nothing_above_threshold_gives_empty_results(tmp_path):
+    """Edge case: no box reaches score_threshold (the reference's boolean_mask is then empty for every class,
+    inference.py:143-152): empty [0,4] / [0] / [0] tensors of the right dtypes, an empty label file, and an
+    image written back unchanged."""
+    heads = [torch.from_numpy(h).cuda() for h in _synthetic_heads(np.random.default_rng(8), 2, (13, 26), -30.0)]
+    anchors = inference.read_anchors(config.tiny_anchors_path)
+    res = inference.predict(heads, anchors, 80, (416, 416), [300, 400])
+    assert len(res) == 2
+    for boxes, scores, classes in res:
+        assert tuple(boxes.shape) == (0, 4) and tuple(scores.shape) == (0,) and tuple(classes.shape) == (0,)
+        assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and classes.dtype == torch.int32
+    det = inference.predict_batch(heads, anchors, 80, (416, 416), [300, 400])
+    assert det.count.cpu().tolist() == [0, 0] and det.cand_count.cpu().tolist() == [0, 0]
+    assert inference.label_lines(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32), (300, 400)) == []
+    img = np.random.default_rng(8).integers(0, 256, (30, 40, 3), dtype=np.uint8)
+    drawn = inference.draw_detections(img, np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32),
+                                      ["x"] * 80)
+    np.testing.assert_array_equal(np.asarray(drawn), img)
+
+
+def test_ragged_image_shapes_equal_batch1_runs():
+    """SURVEY 8a batch note: a batch of B images with B different source shapes returns B triples, each equal
+    (bit for bit: same kernels, per-image letterbox scalars) to the batch-1 run of that image, and to the oracle's
+    NMS of the decoded boxes."""
+    rng = np.random.default_rng(9)
+    hn = _synthetic_heads(rng, 3, (19, 38, 76), 0.0)
+    shapes = np.array([[480, 640], [608, 608], [1080, 1920]], dtype=np.int32)
+    anchors = inference.read_anchors(config.anchors_path)
+    heads = [torch.from_numpy(h).cuda() for h in hn]
+    got = inference.predict(heads, anchors, 80, (608, 608), shapes)
+    assert len(got) == 3
+    total = 0
+    for b in range(3):
+        one = inference.predict([torch.from_numpy(h[b:b + 1]).cuda() for h in hn], anchors, 80, (608, 608), shapes[b])
+        for a, c in zip(got[b], one):
+            assert torch.equal(a, c)
+        ob, os_, oc = odec.predict([h[b:b + 1] for h in hn], anchors, 80, (608, 608), tuple(int(v) for v in shapes[b]),
+                                   config.score_threshold, config.nms_threshold, config.max_boxes)
+        assert len(oc) == got[b][2].shape[0]
+        np.testing.assert_array_equal(got[b][2].cpu().numpy(), oc)
+        np.testing.assert_allclose(got[b][0].cpu().numpy(), ob, rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(got[b][1].cpu().numpy(), os_, rtol=0, atol=2e-6)
+        total += len(oc)
+    assert total > 100
