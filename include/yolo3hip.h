@@ -38,7 +38,8 @@ enum {
     Y3_CONV_RESIDUAL = 2,  /* + residual after the activation (shortcut, :218-227)           */
     Y3_CONV_UPS2X = 4,     /* store each output pixel 2x2 (nearest upsample, :231-239)       */
     Y3_CONV_OUT_F32 = 8,   /* store fp32 regardless of compute dtype (head tensors)          */
-    Y3_CONV_IN_F32 = 16    /* input is fp32 regardless of compute dtype (first layer image)  */
+    Y3_CONV_IN_F32 = 16,   /* input is fp32 regardless of compute dtype (first layer image)  */
+    Y3_CONV_REVERSE = 32   /* scheduling hint, same result: output tiles are walked last to first */
 };
 
 /* One fused convolution: conv (+folded BN) + bias [+ leaky] [+ residual] [2x upsampled store].

@@ -327,3 +327,20 @@ def test_ragged_image_shapes_equal_batch1_runs():
         np.testing.assert_allclose(got[b][1].cpu().numpy(), os_, rtol=0, atol=2e-6)
         total += len(oc)
     assert total > 100
+
+
+def test_snake_tile_order_is_only_a_schedule():
+    """Y3_CONV_REVERSE (consecutive convolutions walk their tiles in opposite directions) changes which workgroup
+    computes which tile, nothing else: heads are bit-identical with and without it."""
+    layers, oi = od.parse_layers(config.yolov3_cfg_path, 80)
+    params = dw.random_params(layers, seed=6)
+    x = torch.from_numpy(np.random.default_rng(6).random((3, 320, 320, 3), dtype=np.float32))
+    outs = []
+    for snake in (True, False):
+        net = build_model.Network(config.yolov3_cfg_path, 80, dtype="bf16", snake=snake)
+        net.set_params(params)
+        plan = net.plan_for(3, 320, 320).plan
+        assert any(op.get("reverse") for op in plan.ops) == snake
+        outs.append([h.cpu().numpy() for h in net(x)])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)

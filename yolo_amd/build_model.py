@@ -14,6 +14,7 @@ the reference's `yolo()` hands to `predict()`.
 torch is used for device memory and streams only; all arithmetic is in libyolo3hip.so.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -107,6 +108,7 @@ class _CompiledPlan(object):
             if op["ups"]: flags |= _lib.CONV_UPS2X
             if op["out_f32"]: flags |= _lib.CONV_OUT_F32
             if op["in_f32"]: flags |= _lib.CONV_IN_F32
+            if op.get("reverse"): flags |= _lib.CONV_REVERSE
             d.flags = flags
             dref = ctypes.byref(d)
             name = ctypes.create_string_buffer(96)
@@ -177,7 +179,8 @@ class _CompiledPlan(object):
 class Network(object):
     """The compiled detector: cfg layers + packed device weights + cached launch plans."""
 
-    def __init__(self, config_path, num_classes, dtype=None, device=None, fuse=True, pad_input=False, stem=True):
+    def __init__(self, config_path, num_classes, dtype=None, device=None, fuse=True, pad_input=False, stem=True,
+                 snake=None):
         self.config_path = config_path
         self.num_classes = num_classes
         self.dtype = dtype or config.compute_dtype
@@ -188,6 +191,8 @@ class Network(object):
         # the MFMA kernel.  Measured slower than the direct kernel at 608 (1.05 vs 0.87 ms), so off by default.
         self.pad_input = pad_input
         self.stem = stem            # fuse Darknet-53's first three convolutions into one launch (bf16 mode)
+        # consecutive convolutions walk their tiles in opposite directions (cache reuse); YOLO_AMD_SNAKE=0 for A/B runs
+        self.snake = (os.environ.get("YOLO_AMD_SNAKE", "1") != "0") if snake is None else bool(snake)
         self.layers, self.out_index = planner.parse_cfg(config_path, num_classes, config.num_anchors_per_scale)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.params = None
@@ -229,7 +234,7 @@ class Network(object):
             if self._packed is None:
                 raise RuntimeError("weights are not loaded: call load_weights(net, path) first")
             plan = planner.build_plan(self.layers, self.out_index, batch, height, width, self.dtype, fuse=self.fuse,
-                                      pad_input=self.pad_input, stem=self.stem)
+                                      pad_input=self.pad_input, stem=self.stem, snake=self.snake)
             cp = _CompiledPlan(self, plan)
             self._plans[key] = cp
         return cp

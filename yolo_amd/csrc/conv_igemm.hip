@@ -70,13 +70,16 @@ __device__ __forceinline__ void row_setup(const ConvArgs &p, int gm, int es, lon
     }
 }
 
-__device__ __forceinline__ int xcd_remap(int orig, int nblk) {
+__device__ __forceinline__ int xcd_remap(int orig, int nblk, bool reverse = false) {
     // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
     // range of logical tiles so that the n-tiles of one m-tile (which share the
     // gathered input) and neighbouring m-tiles (which share halo rows) meet in one L2.
+    // reverse: the XCD walks its range from the end (Y3_CONV_REVERSE: consecutive layers alternate, so a layer
+    // starts on what the previous one wrote last -- still in L2 / Infinity Cache).
     const int q = nblk >> 3, r = nblk & 7, x = orig & 7;
     const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return start + (orig >> 3);
+    const int len = q + (x < r ? 1 : 0), i = orig >> 3;
+    return start + (reverse ? len - 1 - i : i);
 }
 
 __device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base) {
@@ -202,6 +205,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
 // which the hardware ignores, so there is no branch around them.  All residual loads of the wave's tile are
 // issued before the first is used.
 constexpr int CONV_REG_EPILOGUE = 1 << 26;
+// cache policy of the epilogue's stores / residual loads (buffer instruction aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef Y3_STORE_AUX
+#define Y3_STORE_AUX 0
+#endif
+#ifndef Y3_RES_AUX
+#define Y3_RES_AUX 0
+#endif
 #ifndef Y3_RES_EARLY_16THS
 #define Y3_RES_EARLY_16THS 16
 #endif
@@ -223,7 +233,7 @@ __device__ __forceinline__ void conv_residual_load(const ConvArgs &p, u32x4 (&rv
         const int gm = m0 + wm * TM + mi * 16 + frow;
         const bool ok = gm < p.M && nl + pr * 32 < p.Cout8;
         rv[mi][pr] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rs_res, ok ? ((unsigned)gm * (unsigned)p.res_ld + (unsigned)nl) * 2u : OOB, pr * 64, 0));
+            rs_res, ok ? ((unsigned)gm * (unsigned)p.res_ld + (unsigned)nl) * 2u : OOB, pr * 64, Y3_RES_AUX));
     }
 }
 
@@ -280,7 +290,7 @@ __device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&ac
                 const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
                 o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
             }
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, pr * 64, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, pr * 64, Y3_STORE_AUX);
         }
     }
 }
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     }
     int pb = 0;                                  // pipeline buffer the next k-step reads
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
-    const int bid = xcd_remap(tile, p.total_tiles);
+    const int bid = xcd_remap(tile, p.total_tiles, p.flags & Y3_CONV_REVERSE);
     const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_ring_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x, p.flags & Y3_CONV_REVERSE);
     const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 

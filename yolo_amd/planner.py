@@ -179,7 +179,8 @@ def find_stem(layers, inputs, uses, head_of, in_c=3):
     return (i0, i1, i2)
 
 
-def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True, pad_input=False, stem=True):
+def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True, pad_input=False, stem=True,
+               snake=True):
     assert dtype in ("bf16", "fp32")
     es = 2 if dtype == "bf16" else 4
     epc = 16 // es
@@ -407,6 +408,13 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
         for k in ("x", "y", "y2", "a", "b", "res"):
             if k in op:
                 op[k] = resolve(op[k])
+    # Snake order: consecutive convolutions walk their output tiles in opposite directions, so each one starts
+    # on the part of its input that the previous one wrote last (still in L2 / Infinity Cache) -- same results.
+    k = 0
+    for op in ops:
+        if op["kind"] in ("conv", "stem"):
+            op["reverse"] = bool(snake and (k & 1) and op["kind"] == "conv")
+            k += 1
     return plan
 
 
