@@ -212,6 +212,12 @@ constexpr int CONV_REG_EPILOGUE = 1 << 26;
 #ifndef Y3_RES_AUX
 #define Y3_RES_AUX 0
 #endif
+#ifndef Y3_XPF_MAX_ACC
+#define Y3_XPF_MAX_ACC 64  // largest accumulator tile (registers per lane) that gets the cross-tile prefetch
+#endif
+#ifndef Y3_XPF
+#define Y3_XPF 0          // cross-tile prefetch in the persistent kernels (measured +3..7 % SLOWER on the 128-row tiles: off)
+#endif
 #ifndef Y3_RES_EARLY_16THS
 #define Y3_RES_EARLY_16THS 16
 #endif
@@ -295,8 +301,18 @@ __device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&ac
     }
 }
 
+// Waves per SIMD the launcher counts on (workgroups per CU by LDS x waves per workgroup / 4 SIMDs).  Without it
+// the compiler budgets 512 registers for a 4-wave workgroup, and a kernel that drifts past 256 (VGPR + AGPR)
+// silently halves its occupancy: measured 1.5x slower on the 128x128 tile.
+constexpr int conv_waves_per_simd(int lds_bytes, int waves) {
+    const int wg = lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 53 * 1024 ? 2 : 3);
+    return (wg * waves + 3) / 4;
+}
+
 template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, bool INTERLEAVE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
+__attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(2 * (BM + BN) * 128, WAVES_M * WAVES_N), conv_waves_per_simd(2 * (BM + BN) * 128, WAVES_M * WAVES_N))))
+void conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;   // threads
     constexpr int ES = BF16 ? 2 : 4;             // element bytes
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
@@ -328,33 +344,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__builtin_amdgcn_s_memrealtime() - t0 < p.delay_ticks) __builtin_amdgcn_s_sleep(64);
     }
-    int pb = 0;                                  // pipeline buffer the next k-step reads
-    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
-    const int bid = xcd_remap(tile, p.total_tiles, p.flags & Y3_CONV_REVERSE);
-    const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    // ---- loader set-up: thread owns LDS chunk slot (tid&7) of rows (tid>>3) + LROWS*i --------
+    // ---- loader state: thread owns LDS chunk slot (tid&7) of rows (tid>>3) + LROWS*i --------------
     const int lrow = tid >> 3;
     const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * EPC;   // source chunk of this LDS slot
-
-    long a_base[A_IT];
-    unsigned a_mask[A_IT];
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int gm = m0 + lrow + LROWS * i;
-        a_base[i] = 0;
-        a_mask[i] = 0;
-        if (gm < p.M) row_setup(p, gm, ES, a_base[i], a_mask[i]);
-    }
-    long w_off[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) w_off[i] = ((long)(n0 + lrow + LROWS * i) * p.Kpad + kc) * ES;
-
     // k position of this thread's chunk: tap = k / Cin, cin = k % Cin, advanced by BKE per k-step
     // without a division (step_tap = BKE / Cin, step_cin = BKE % Cin come from the host).
-    int tap = kc / p.Cin;
-    int cin = kc - tap * p.Cin;
+    const int tap0 = kc / p.Cin, cin0 = kc - tap0 * p.Cin;
+    long a_base[A_IT];
+    unsigned a_mask[A_IT];
+    long w_off[B_IT];
+    int tap = 0, cin = 0;
+    auto tile_setup = [&](int tile, int &tm0, int &tn0) {
+        const int bid = xcd_remap(tile, p.total_tiles, p.flags & Y3_CONV_REVERSE);
+        const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
+        tm0 = mt * BM;
+        tn0 = nt * BN;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int gm = tm0 + lrow + LROWS * i;
+            a_base[i] = 0;
+            a_mask[i] = 0;
+            if (gm < p.M) row_setup(p, gm, ES, a_base[i], a_mask[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) w_off[i] = ((long)(tn0 + lrow + LROWS * i) * p.Kpad + kc) * ES;
+        tap = tap0;
+        cin = cin0;
+    };
 
     // One k-step of loads is NP = A_IT + B_IT LDS-DMA pieces (1 KiB per wave each).  An LDS-DMA
     // instruction holds the issuing wave for ~60-180 cycles, so the pieces are not issued in a
@@ -389,6 +405,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
         }
     };
 
+    // Cross-tile prefetch (register epilogue only: the other epilogue stages through the pipeline buffers): the
+    // last k-step of a tile sets the loader up for the workgroup's next tile and fetches its first k-step, so
+    // those loads are queued ahead of the epilogue's stores and land under them; the next tile's first k-step
+    // then waits for all but the stores (vmcnt counts in order: the XPF_STORES youngest are the stores).
+    constexpr bool XPF_OK = BF16 && NI % 2 == 0 && Y3_XPF != 0 && MI * NI * 4 <= Y3_XPF_MAX_ACC && WAVES_M * WAVES_N == 4;
+    constexpr int XPF_STORES = MI * (NI / 2);
+    static_assert(XPF_STORES < 64, "vmcnt range");
+    int pb = 0;                                  // pipeline buffer the next k-step reads
+    int m0n = 0, n0n = 0;                        // tile the loader is set up for
+    bool primed = false;                         // ... and whose first k-step is already in flight
+    bool counted = false;                        // the next k-step waits with vmcnt(XPF_STORES)
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    // (after a cross-tile prefetch the set-up is simply recomputed: keeping it in registers through the epilogue
+    // would cost the big tiles ~40 registers they do not have)
+    tile_setup(tile, m0n, n0n);
+    stage_begin();
+    if (!primed) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) piece(q, 0, pb);       // free: every wave is past the barrier of the last k-step
+    }
+    const int m0 = m0n, n0 = n0n;
+
     // ---- main loop ------------------------------------------------------------------------
     const bool reg_epi = BF16 && (p.flags & CONV_REG_EPILOGUE);     // then the bias is the accumulators' initial value
     f32x4 acc[NI][MI];
@@ -409,10 +447,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
     constexpr int RES_EARLY = (BF16 && NI % 2 == 0 && MI * NI * 4 <= 96) ? (MI * (NI / 2) * Y3_RES_EARLY_16THS) / 16 : 0;
     auto kstep = [&](int kt, auto prefetch, auto early) {
         constexpr bool PF = decltype(prefetch)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of tile kt has landed
-        __syncthreads();                                    // everyone's has; buffer (kt+1)&1 is free
-        if constexpr (PF) stage_begin();
+        // this wave's LDS-DMA of k-step kt has landed (after a cross-tile prefetch the epilogue's stores may remain)
+        if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPF_STORES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        counted = false;
+        __syncthreads();                                    // everyone's has; the other buffer is free
         early();
+        if constexpr (PF) stage_begin();
         const char *As = smem + pb * STAGE;
         const char *Bs = As + BM * 128;
 #pragma unroll
@@ -453,19 +494,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
         pb ^= 1;
     };
 
-    stage_begin();
-#pragma unroll
-    for (int q = 0; q < NP; ++q) piece(q, 0, pb);       // free: every wave is past the barrier of the last k-step
     for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, [] {});
     u32x4 rv[MI][NI % 2 == 0 ? NI / 2 : 1];
-    kstep(nk - 1, std::false_type{}, [&] {
+    auto res_early = [&] {
         if constexpr (RES_EARLY > 0) {
             if (reg_epi && (p.flags & Y3_CONV_RESIDUAL)) {
                 conv_residual_load<TM, TN, MI, NI, 0, RES_EARLY>(p, rv, m0, n0, lane, wm, wn);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    });
+    };
+    const int next_tile = tile + (int)gridDim.x;
+    primed = XPF_OK && reg_epi && next_tile < p.total_tiles && !(p.flags & ((1 << 27) | (1 << 25)));
+    if (primed) {
+        kstep(-1, std::true_type{}, [&] {        // "k-step kt + 1" of the prefetch = k-step 0 of the next tile
+            res_early();
+            int m0x, n0x;
+            tile_setup(next_tile, m0x, n0x);
+        });
+        counted = true;
+    } else {
+        kstep(nk - 1, std::false_type{}, res_early);
+    }
 
     if (p.flags & (1 << 27)) {          // timing experiment: no epilogue (one store keeps the accumulators live)
         float sacc = 0.f;
@@ -493,7 +543,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(cons
 // 64-byte rows: four rows share a 256-byte bank row, chunk c of row r sits at slot
 // c ^ (3 * ((r >> 2) & 1)), which keeps the ds_read_b128 fragment reads conflict free.
 template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, int RING>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_ring_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
+__attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(RING * (BM + BN) * 64, WAVES_M * WAVES_N), conv_waves_per_simd(RING * (BM + BN) * 64, WAVES_M * WAVES_N))))
+void conv_igemm_ring_kernel(const ConvArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int ES = BF16 ? 2 : 4;
     constexpr int EPC = 16 / ES;
@@ -793,6 +845,10 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
     int tile = g_conv_tile;
     if (tile == 0) {
         tile = 128;
+        // 65..128 output channels, bf16, enough tiles for two workgroups per CU: the 256-pixel x 128-channel ring
+        // kernel (half the weight re-reads of the 128x128 tile; measured -3..-6 % on the 1x1 256->128 and
+        // 3x3 64->128 layers once its occupancy was pinned to two workgroups per CU)
+        if (d->n_pad == 128 && d->dtype == Y3_BF16 && M >= 256L * 512) tile = 257;
         if (d->n_pad % 256 == 0) {
             const long cus = 256;
             auto rounds = [&](long bm, long bnn, long per_cu) {
@@ -910,6 +966,7 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     if (g_conv_debug & 8) a.flags |= 1 << 29;  // timing experiment: no A loads at all (garbage results)
     if (g_conv_debug & 16) a.flags |= 1 << 28; // timing experiment: no B loads at all (garbage results)
     if (g_conv_debug & 32) a.flags |= 1 << 27; // timing experiment: no epilogue (no results)
+    if (g_conv_debug & 256) a.flags |= 1 << 25; // experiment: no cross-tile prefetch
     const int bke = bf16 ? 64 : 32;
     a.n_tiles = 0;
     a.step_tap = bke / d->in_c;
