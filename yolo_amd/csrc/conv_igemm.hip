@@ -471,13 +471,13 @@ void conv_igemm_kernel(const ConvArgs p) {
             for (int j = 0; j < NMF; ++j) {
                 if constexpr (PF) {
                     if (ks == 0) {
+                        // piece q goes before MFMA group floor(q * NMF / NP): q in [ceil(j NP / NMF), ceil((j+1) NP / NMF))
 #pragma unroll
-                        for (int q = 0; q < NP; ++q)
-                            if (j == (q * NMF) / NP) {
-                                if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
-                                piece(q, kt + 1, pb ^ 1);
-                                if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
-                            }
+                        for (int q = (j * NP + NMF - 1) / NMF; q < ((j + 1) * NP + NMF - 1) / NMF; ++q) {
+                            if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+                            piece(q, kt + 1, pb ^ 1);
+                            if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
                 const int ni = j / MI, mi = j % MI;
@@ -519,7 +519,11 @@ void conv_igemm_kernel(const ConvArgs p) {
 
     if (p.flags & (1 << 27)) {          // timing experiment: no epilogue (one store keeps the accumulators live)
         float sacc = 0.f;
-        for (int ni = 0; ni < NI; ++ni) for (int mi = 0; mi < MI; ++mi) sacc += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) sacc += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
+        }
         if (sacc == 123.456f) *(float *)p.out = sacc;
         continue;
     }
