@@ -19,6 +19,19 @@
 // the SOURCE address (LDS-DMA writes lane-linear) and on the fragment read, which
 // makes the ds_read_b128 fragment reads bank-conflict free.  Zero padding comes
 // from pointing the lane's source address at a zero page.
+//
+// What runs by default (conv_variant picks per layer; everything else below is a measured alternative that no
+// layer selects, reachable through y3_set_conv_tile for A/B runs -- results in DESIGN.md section 3.1):
+//   256  conv_igemm_kernel<256,256, 8 waves>   Cout >= 256, few rounds         persistent, register epilogue
+//   192  conv_igemm_kernel<192,256, 8 waves>   same, when it saves a round     persistent, register epilogue
+//   257  conv_igemm_ring_kernel<256,128,RING 3> 65..128 output channels (bf16)  two workgroups per CU
+//   128 / 64 / 32  conv_igemm_kernel<128,BN>   small layers, fp32 mode         2-3 workgroups per CU
+//   direct  conv_direct_kernel                 Cin = 3 (first layer) when the fused stem is not used
+// Alternatives: 129 (128x256), 258 (256x128, 8 waves), 130/131 (128x128 ring), debug bit 4 (ring for 256/128).
+// Debug bits (high half of y3_set_conv_tile): 1/8/16/32 timing experiments that skip loads or the epilogue
+// (results are garbage), 2 no interleave, 64 force the LDS epilogue, 128 one workgroup per tile.
+// Compile-time switches, default off because they measured slower: Y3_XPF (cross-tile prefetch),
+// Y3_STORE_AUX / Y3_RES_AUX (cache policy of the epilogue's stores and residual loads).
 #include "common.h"
 #include <type_traits>
 
