@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24, help="timed images of the CPU baseline (plus 1 warm-up)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one HIP graph (yolo_amd.graph.GraphedDetector): the serving mode at small "
+                         "batch; per-kernel events, hence the roofline object, are not available in it")
     return ap.parse_args()
 
 
@@ -112,7 +115,18 @@ def main():
     images = torch.rand((hi - lo, S, S, 3), generator=gen, dtype=torch.float32).to(dev)
     chunk = args.chunk or None
 
+    graphed = None
+    if args.graph:
+        from yolo_amd.graph import GraphedDetector
+        args.no_kernel_events = True
+        graphed = GraphedDetector(net, anchors, config.num_classes, (S, S), batch=hi - lo, score_threshold=config.score_threshold,
+                                  iou_threshold=config.nms_threshold, max_boxes=config.max_boxes)
+        graphed.images.copy_(images)
+        graphed.capture((S, S))
+
     def step(trace=None, trace_filter=None):
+        if graphed is not None:
+            return graphed()
         heads = net.forward(images, chunk=chunk, trace=trace, trace_filter=trace_filter)
         return inference.predict_batch(heads, anchors, config.num_classes, (S, S), (S, S))
 
@@ -169,7 +183,7 @@ def main():
                                    "decode + per-class NMS (score>=%.3g, iou>0.3, max 51/class)"
                                    % (args.model, S, S, B, args.dtype, args.score_threshold),
                        "global_batch": world * B, "parallelism": "dp%d (image-sharded, no data-path collective)" % world,
-                       "chunk": chunk or B, "conv_gflop_per_image": round(gflop_img, 3),
+                       "chunk": chunk or B, "launch": "hip graph replay" if args.graph else "eager", "conv_gflop_per_image": round(gflop_img, 3),
                        "mean_detections_per_image": round(float(counts.float().mean().item()), 2)},
             "conv_mfma_util_pct_end_to_end": round(100.0 * gflop_img * value / world / 1e3 /
                                                    (BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS), 2),

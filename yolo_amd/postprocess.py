@@ -86,10 +86,10 @@ class PostProcessor(object):
             self._ws[key] = ws
         return ws
 
-    def __call__(self, heads, image_shapes):
-        """heads: list of 2 or 3 head tensors [B,g,g,A*(5+C)] (coarse first);
-        image_shapes: (h, w) for all images or a [B,2] array (inference.py:218)."""
-        lib = _lib.load()
+    def prepare(self, heads, image_shapes):
+        """Host side of a call: validates the head tensors, builds the decode descriptor, makes sure the
+        workspace exists and uploads the per-image letterbox scalars when the image shapes changed.  Nothing
+        here may run under HIP graph capture (allocation, host -> device copy); `launch` is what a graph holds."""
         views = [_head_view(h) for h in heads]
         B = views[0][0].shape[0]
         device = views[0][0].device
@@ -116,7 +116,11 @@ class PostProcessor(object):
         d.score_threshold = self.score_threshold
         d.boxes_per_image = N
         ws = self._workspace(B, N, device)
+        self.set_image_shapes(ws, B, image_shapes)
+        return views, d, ws, (B, N, L)
 
+    def set_image_shapes(self, ws, B, image_shapes):
+        """(h, w) for all images or a [B,2] array (inference.py:218) -> letterbox scalars on the device."""
         shapes = np.asarray(image_shapes, dtype=np.float32)
         if shapes.ndim == 1:
             shapes = np.broadcast_to(shapes, (B, 2))
@@ -127,6 +131,14 @@ class PostProcessor(object):
                 lb[b, :3] = letterbox_params(self.input_shape, shapes[b])
             ws["letterbox"].copy_(torch.from_numpy(lb), non_blocking=False)
             ws["letterbox_key"] = lb_key
+
+    def launch(self, views, d, ws, dims):
+        """Device side: counter reset, decode, NMS (4 launches), pack -- asynchronous on the current stream,
+        no allocation, no host copy: capturable in a HIP graph."""
+        lib = _lib.load()
+        B, N, L = dims
+        C = self.num_classes
+        device = views[0][0].device
         ws["counts"].zero_()
         stream = torch.cuda.current_stream(device).cuda_stream
         hp = [v[0].data_ptr() for v in views] + [None] * (3 - L)
@@ -146,3 +158,8 @@ class PostProcessor(object):
         self._keep = views
         return Detections(ws["out_boxes"], ws["out_scores"], ws["out_classes"], ws["out_count"], ws["kept_idx"],
                           ws["kept_count"], ws["kept_rank"], ws["records"], cand_count)
+
+    def __call__(self, heads, image_shapes):
+        """heads: list of 2 or 3 head tensors [B,g,g,A*(5+C)] (coarse first);
+        image_shapes: (h, w) for all images or a [B,2] array (inference.py:218)."""
+        return self.launch(*self.prepare(heads, image_shapes))
