@@ -12,6 +12,10 @@ import os
 import sys
 
 
+SQ_COUNTERS = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+               "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")
+
+
 def short(name):
     name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0]
@@ -38,6 +42,7 @@ def main():
                                            total_ms=float(r["TotalDurationNs"]) / 1e6, pct=float(r["Percentage"]))
     fetch = load_counter(os.path.join(root, "pmc_fetch"), "FETCH_SIZE")
     write = load_counter(os.path.join(root, "pmc_write"), "WRITE_SIZE")
+    sq = {c: load_counter(os.path.join(root, "pmc_sq"), c) for c in SQ_COUNTERS}
     out = {}
     for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"]):
         if s["pct"] < 0.05:
@@ -49,8 +54,29 @@ def main():
             e["write_bytes_per_launch"] = write[k][0] * 1024 / write[k][1]
         if "fetch_bytes_per_launch_corrected" in e and "write_bytes_per_launch" in e:
             e["hbm_bytes_per_launch"] = e["fetch_bytes_per_launch_corrected"] + e["write_bytes_per_launch"]
+        # SQ pass (own run): MFMA-pipe busy share and where wave time goes.  GRBM_GUI_ACTIVE is summed over the
+        # 8 XCDs (MI355X_MICROARCH.md, DVFS give-back), SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs;
+        # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_ANY are in quad-cycles and disjoint shares of wave time.
+        g = sq["GRBM_GUI_ACTIVE"].get(k)
+        if g and g[1]:
+            cyc = g[0] / g[1] / 8.0
+            e["gpu_cycles_per_launch"] = cyc
+            m = sq["SQ_VALU_MFMA_BUSY_CYCLES"].get(k)
+            if m and m[1] and cyc > 0:
+                e["mfma_busy_pct"] = 100.0 * (m[0] / m[1]) / (cyc * 1024.0)
+            w = sq["SQ_WAVE_CYCLES"].get(k)
+            if w and w[0] > 0:
+                for name, key in (("SQ_WAIT_ANY", "wave_wait_any_pct"), ("SQ_WAIT_INST_ANY", "wave_wait_inst_pct"),
+                                  ("SQ_ACTIVE_INST_ANY", "wave_active_inst_pct")):
+                    c = sq[name].get(k)
+                    if c:
+                        e[key] = 100.0 * c[0] / w[0]
+            a, b = sq["SQ_LDS_IDX_ACTIVE"].get(k), sq["SQ_LDS_BANK_CONFLICT"].get(k)
+            if a and b and a[0] > 0:
+                e["lds_bank_conflict_pct"] = 100.0 * b[0] / a[0]
         out[k] = e
-    json.dump({"note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; per launch = sum / dispatches",
+    json.dump({"note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; per launch = sum / dispatches; mfma_busy_pct = "
+                       "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); wave_* = share of SQ_WAVE_CYCLES",
                "kernels": out}, sys.stdout, indent=1)
 
 
