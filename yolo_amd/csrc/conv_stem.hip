@@ -18,6 +18,7 @@
 //   4. conv C straight from those registers.
 // Weights are the MFMA A operand, pixels the B operand, as in conv_igemm.hip.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -27,6 +28,8 @@ constexpr int AP_W = 2 * TW + 1;               // 33 columns
 constexpr int IM_H = AP_H + 2;                 // 19 image rows
 constexpr int IM_W = AP_W + 2;                 // 35 image columns
 constexpr int IM_PITCH = 36;                   // LDS patch row pitch in pixels; a pixel is 4 bf16 (r, g, b, 0) = 8 bytes
+constexpr int IM_ODD = (IM_PITCH / 2) * 8;     // a row holds its even columns first, then (144 bytes on) its odd ones:
+                                               // lane frow reads columns 2*frow.. -> 8-byte lane stride, no bank conflict
 constexpr int IM_PIX = IM_H * IM_W;            // 665
 constexpr int IMG_LOADS = (IM_PIX + 255) / 256;   // 3 pixels per thread
 constexpr int P_BYTES = 3 * AP_H * TW * 64;    // 52 224
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
                 *(bf16x8 *)(wa_s + (kb * 2 + nb) * 1024) = w;
             }
     }
-    if (tid < IM_H) *(uint2 *)(img + (tid * IM_PITCH + IM_W) * 8) = uint2{0u, 0u};      // the pad column stays zero
+    if (tid < IM_H) *(uint2 *)(img + tid * IM_PITCH * 8 + IM_ODD + (IM_W >> 1) * 8) = uint2{0u, 0u};      // the pad column (35, odd) stays zero
     if (tid < 32) bias_s[tid] = p.b0[tid];
     if (tid < 64) bias_s[32 + tid] = p.b1[tid];
     if constexpr (HAS_C) {
@@ -168,13 +171,13 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
     // Waves 0, 2 take the even patch columns px = 2*frow, waves 1, 3 the odd ones px = 2*frow + 1; patch rows
     // py = (wave >> 1) + 2j.  Column 32 (17 pixels) is left over: wave 2 takes its rows 0..15, wave 3 row 16.
     auto p_addr = [&](int kw, int py, int ox, int nb) {     // byte offset in P of this lane's 8 bytes of n-block nb
-        const int chunk = nb * 2 + (fq >> 1), sw = ((ox >> 3) & 1) << 1;
+        const int chunk = nb * 2 + (fq >> 1), sw = (ox >> 1) & 3;
         return ((kw * AP_H + py) * TW + ox) * 64 + ((chunk ^ sw) * 16) + (fq & 1) * 8;
     };
     const int par = wave & 1, pyw = wave >> 1;
     const int rowsel = fq < 3 ? fq : 0;
     const int px_l = 2 * frow + par;
-    const int rd_l = ((pyw + rowsel) * IM_PITCH + px_l) * 8;                   // + j * 2 * IM_PITCH * 8
+    const int rd_l = (pyw + rowsel) * IM_PITCH * 8 + (frow + par) * 8;          // even-plane slot of column px_l (par 0) / px_l + 1 (par 1); + j * 2 * IM_PITCH * 8
     const int wA0 = p_addr(par, pyw, frow, 0), wA1 = p_addr(par, pyw, frow, 1);   // + j * 2 * TW * 64
     // even columns also feed P[2][.][ox - 1]; lane frow = 0 has no such slot and repeats its first store
     // (same bytes, same address) instead, so that the second store needs no per-lane mask
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         uint2 o;
         o.x = ok ? pack_bf16x2(pre[q][0], pre[q][1]) : 0u;
         o.y = ok ? pack_bf16x2(pre[q][2], 0.0f) : 0u;
-        if (i < IM_PIX) *(uint2 *)(img + (rr * IM_PITCH + cc) * 8) = o;
+        if (i < IM_PIX) *(uint2 *)(img + rr * IM_PITCH * 8 + (cc & 1) * IM_ODD + (cc >> 1) * 8) = o;
     }
     };
     int t = blockIdx.x;
@@ -214,21 +217,27 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         const int oy0 = ty * TH, ox0 = tx * TW;
 
         __syncthreads();            // patch visible; every wave is past step 3 of the previous tile
+        bf16x8 wa[4];               // conv A's weight fragments: read once per tile, not once per block
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[i] = *(const bf16x8 *)(wa_s + i * 1024);
         // unconditional (the last iteration re-loads a valid tile for nobody): a conditional prefetch makes the
         // compiler copy the loaded registers at the join, which waits for the loads right here
         load_patch(min(t + (int)gridDim.x, total - 1));
 
         // ---- 2. conv A on the 17 x 33 patch -> P[kw][row][ox] --------------------------------
-        auto conv_a_block = [&](const char *rd, bool in_img, char *a0, char *a1, bool do_a, char *b0, char *b1, bool do_b) {
-            const uint2 r0 = *(const uint2 *)rd, r1 = *(const uint2 *)(rd + 8);
-            const uint2 r2 = *(const uint2 *)(rd + 16), r3 = *(const uint2 *)(rd + 24);
+        // odd = the block's first column is odd (waves 1, 3): columns c, c+1, c+2, c+3 are then the odd plane's slot
+        // before rd, rd itself, the odd plane's slot at rd, and the even plane's next slot
+        auto conv_a_block = [&](auto odd, const char *rd, bool in_img, char *a0, char *a1, bool do_a, char *b0, char *b1, bool do_b) {
+            constexpr bool ODD = decltype(odd)::value;
+            const uint2 r0 = *(const uint2 *)(rd + (ODD ? IM_ODD - 8 : 0)), r1 = *(const uint2 *)(rd + (ODD ? 0 : IM_ODD));
+            const uint2 r2 = *(const uint2 *)(rd + (ODD ? IM_ODD : 8)), r3 = *(const uint2 *)(rd + (ODD ? 8 : IM_ODD + 8));
             const bf16x8 x0 = __builtin_bit_cast(bf16x8, u32x4{r0.x, r0.y, r1.x, r1.y});
             const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{r2.x, r2.y, r3.x, r3.y});
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 f32x4 a = *(const f32x4 *)(bias_s + nb * 16 + fq * 4);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8 *)(wa_s + nb * 1024), x0, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8 *)(wa_s + (2 + nb) * 1024), x1, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb], x0, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2 + nb], x1, a, 0, 0, 0);
                 const f32x4 v = act(a, slope_a);
                 uint2 o;                        // outside the image conv A's output is conv B's zero padding
                 o.x = in_img ? pack_bf16x2(v[0], v[1]) : 0u;
@@ -239,25 +248,29 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         };
         {
             const bool ax_ok = (unsigned)(2 * ox0 - 1 + px_l) < (unsigned)p.W;
+            auto columns = [&](auto odd) {
 #pragma unroll
-            for (int j = 0; j < (AP_H + 1) / 2; ++j) {
-                const int py = pyw + 2 * j;                       // wave-uniform
-                if (py < AP_H) {
-                    const bool ay_ok = (unsigned)(2 * oy0 - 1 + py) < (unsigned)p.H;
-                    conv_a_block(img + rd_l + j * (2 * IM_PITCH * 8), ay_ok && ax_ok, P + wA0 + j * (2 * TW * 64),
-                                 P + wA1 + j * (2 * TW * 64), true, P + wB0 + j * (2 * TW * 64), P + wB1 + j * (2 * TW * 64), doB);
+                for (int j = 0; j < (AP_H + 1) / 2; ++j) {
+                    const int py = pyw + 2 * j;                       // wave-uniform
+                    if (py < AP_H) {
+                        const bool ay_ok = (unsigned)(2 * oy0 - 1 + py) < (unsigned)p.H;
+                        conv_a_block(odd, img + rd_l + j * (2 * IM_PITCH * 8), ay_ok && ax_ok, P + wA0 + j * (2 * TW * 64),
+                                     P + wA1 + j * (2 * TW * 64), true, P + wB0 + j * (2 * TW * 64), P + wB1 + j * (2 * TW * 64), doB);
+                    }
                 }
-            }
+            };
+            if (par) columns(std::true_type{});
+            else columns(std::false_type{});
             if (wave >= 2) {                                      // left-over column 32: lane frow <-> patch row py_x
                 int fr = frow;
                 asm volatile("" : "+v"(fr));
                 const int py_x = wave == 2 ? fr : 16;
                 const bool do_x = wave == 2 || frow == 0;
-                const int rd_x = ((py_x + rowsel) * IM_PITCH + 32) * 8;
+                const int rd_x = (py_x + rowsel) * IM_PITCH * 8 + 16 * 8;      // column 32: even plane, slot 16
                 const int dump_x = P_BYTES + IMG_BYTES + BIAS_BYTES + WC_BYTES + WA_BYTES + WB8_BYTES + lane * 8;
                 const int wX0 = do_x ? p_addr(2, py_x, 15, 0) : dump_x, wX1 = do_x ? p_addr(2, py_x, 15, 1) : dump_x;
                 const bool in_x = (unsigned)(2 * oy0 - 1 + py_x) < (unsigned)p.H && (unsigned)(2 * ox0 + 31) < (unsigned)p.W;
-                conv_a_block(img + rd_x, in_x, nullptr, nullptr, false, P + wX0, P + wX1, true);
+                conv_a_block(std::false_type{}, img + rd_x, in_x, nullptr, nullptr, false, P + wX0, P + wX1, true);
             }
         }
         __syncthreads();
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         // ---- 3. conv B: 9 taps, two output rows per wave ---------------------------------------
         // one output row at a time (four independent accumulator chains are enough to pace the MFMA pipe,
         // and the second row's accumulators would not fit next to the 144 weight registers)
-        const int slot = (fq ^ (((frow >> 3) & 1) << 1)) * 16;
+        const int slot = (fq ^ ((frow >> 1) & 3)) * 16;       // same swizzle as p_addr: conflict-free ds_read_b128, 2-way ds_write_b64
         const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;       // first of this lane's 8 channels in a pair
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
