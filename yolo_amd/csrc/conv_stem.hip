@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         bf16x8 wa[4];               // conv A's weight fragments: read once per tile, not once per block
 #pragma unroll
         for (int i = 0; i < 4; ++i) wa[i] = *(const bf16x8 *)(wa_s + i * 1024);
+        const f32x4 ba[2] = {*(const f32x4 *)(bias_s + fq * 4), *(const f32x4 *)(bias_s + 16 + fq * 4)};
         // unconditional (the last iteration re-loads a valid tile for nobody): a conditional prefetch makes the
         // compiler copy the loaded registers at the join, which waits for the loads right here
         load_patch(min(t + (int)gridDim.x, total - 1));
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
             const bf16x8 x1 = __builtin_bit_cast(bf16x8, u32x4{r2.x, r2.y, r3.x, r3.y});
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                f32x4 a = *(const f32x4 *)(bias_s + nb * 16 + fq * 4);
+                f32x4 a = ba[nb];
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb], x0, a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2 + nb], x1, a, 0, 0, 0);
                 const f32x4 v = act(a, slope_a);
@@ -280,6 +281,9 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
         // and the second row's accumulators would not fit next to the 144 weight registers)
         const int slot = (fq ^ ((frow >> 1) & 3)) * 16;       // same swizzle as p_addr: conflict-free ds_read_b128, 2-way ds_write_b64
         const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;       // first of this lane's 8 channels in a pair
+        bf16x8 wb8[4];              // ninth tap: read once per tile (the wave's two output rows share it)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) wb8[nb] = *(const bf16x8 *)(wa_s + WA_BYTES + nb * 1024);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             f32x4 acc[4];
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const StemArgs p) {
                     const bf16x8 xf = *(const bf16x8 *)(P + ((kw * AP_H + row) * TW + frow) * 64 + slot);
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) {
-                        const bf16x8 w = kh * 3 + kw < 8 ? wb[(kh * 3 + kw) & 7][nb] : *(const bf16x8 *)(wa_s + WA_BYTES + nb * 1024);
+                        const bf16x8 w = kh * 3 + kw < 8 ? wb[(kh * 3 + kw) & 7][nb] : wb8[nb];
                         acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xf, acc[nb], 0, 0, 0);
                     }
                 }
