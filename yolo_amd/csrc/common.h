@@ -40,6 +40,17 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float leaky01(float x) { return x > 0.0f ? x : 0.1f * x; }
 // Same value bit for bit for every non-NaN x (signed zeros included): max(x, 0.1x) as a median with +inf,
 // two instructions instead of three and no canonicalisation.
+// max(x, slope * x) = leaky-ReLU (slope 0.1) or identity (slope 1), written as the machine instruction: through
+// fmed3 / fmaxf the compiler first canonicalises both inputs (v_max_f32 x, x, x -- the signalling-NaN quieting
+// that v_max_f32 in IEEE mode does by itself), three VALU operations per element instead of two.  Same value
+// as x > 0 ? x : 0.1f * x for every non-NaN x.
+__device__ __forceinline__ float leaky_max(float x, float slope) {
+    const float t = slope * x;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
+    return r;
+}
+
 __device__ __forceinline__ float leaky01_fast(float x) { return __builtin_amdgcn_fmed3f(x, 0.1f * x, __builtin_inff()); }
 
 // DPP moves within a row of 16 lanes: CTRL 0x120 + n = row_ror:n (rotate), 0x150 + n = row_newbcast:n

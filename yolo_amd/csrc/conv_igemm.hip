@@ -280,8 +280,8 @@ __device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&ac
             f32x4 x = acc[2 * pr][mi], y = acc[2 * pr + 1][mi];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                x[j] = __builtin_amdgcn_fmed3f(x[j], slope * x[j], __builtin_inff());
-                y[j] = __builtin_amdgcn_fmed3f(y[j], slope * y[j], __builtin_inff());
+                x[j] = leaky_max(x[j], slope);
+                y[j] = leaky_max(y[j], slope);
             }
             u32x4 o;
             if (has_res) {

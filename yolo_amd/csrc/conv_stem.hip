@@ -52,12 +52,12 @@ struct StemArgs {
     unsigned out1_bytes, out2_bytes;
 };
 
-// leaky-ReLU as max(x, slope*x) (slope 0.1, or 1 for a linear layer): a median with +inf, branch-free.
+// leaky-ReLU as max(x, slope*x) (slope 0.1, or 1 for a linear layer; common.h leaky_max), branch-free.
 // Bit-identical to x > 0 ? x : 0.1x for every non-NaN x.  The bias is not added here: it is the initial
 // value of the MFMA accumulator (one LDS read instead of an LDS read and four adds).
 __device__ __forceinline__ f32x4 act(f32x4 v, float slope) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], slope * v[j], __builtin_inff());
+    for (int j = 0; j < 4; ++j) v[j] = leaky_max(v[j], slope);
     return v;
 }
 
