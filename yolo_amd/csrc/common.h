@@ -51,6 +51,18 @@ __device__ __forceinline__ float leaky_max(float x, float slope) {
     return r;
 }
 
+// fmaxf / fminf without the compiler's input canonicalisation (see leaky_max); identical for non-NaN inputs.
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float leaky01_fast(float x) { return __builtin_amdgcn_fmed3f(x, 0.1f * x, __builtin_inff()); }
 
 // DPP moves within a row of 16 lanes: CTRL 0x120 + n = row_ror:n (rotate), 0x150 + n = row_newbcast:n

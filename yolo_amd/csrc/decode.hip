@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void decode_lane_kernel(const DecodeArgs2
 #pragma unroll
                 for (int u = 0; u < 16; ++u) v[u] = tl[5 + c + u];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) tmax = fmaxf(tmax, v[u]);
+                for (int u = 0; u < 16; ++u) tmax = vmax_raw(tmax, v[u]);
             }
             for (; c < C; ++c) tmax = fmaxf(tmax, tl[5 + c]);
         }

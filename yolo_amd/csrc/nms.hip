@@ -57,8 +57,8 @@ __device__ __forceinline__ NBox norm_box(const f32x4 b) {
 }
 __device__ __forceinline__ bool iou_gt_norm(const NBox &i, const NBox &j, float thr) {
     if (i.area <= 0.0f || j.area <= 0.0f) return false;
-    const float iymin = fmaxf(i.ymin, j.ymin), ixmin = fmaxf(i.xmin, j.xmin);
-    const float iymax = fminf(i.ymax, j.ymax), ixmax = fminf(i.xmax, j.xmax);
+    const float iymin = vmax_raw(i.ymin, j.ymin), ixmin = vmax_raw(i.xmin, j.xmin);      // boxes are finite: raw min/max
+    const float iymax = vmin_raw(i.ymax, j.ymax), ixmax = vmin_raw(i.xmax, j.xmax);
     const float inter = fmaxf(iymax - iymin, 0.0f) * fmaxf(ixmax - ixmin, 0.0f);
     const float iou = inter / (i.area + j.area - inter);
     return iou > thr;
