@@ -222,3 +222,27 @@ def test_conv_tile256_equals_tile128(case, dtype):
                 np.testing.assert_array_equal(outs[reg_family[0]], outs[lds_family[0]])
     finally:
         lib.y3_set_conv_tile(0)
+
+
+def test_conv_cout64_tile_variants_agree():
+    """33..64 output channels with many pixels: the default 256x64 tile (260), the 128x64 tile (64) and the ring
+    form (261) against the oracle and bit for bit against each other (same register epilogue, same k order)."""
+    from yolo_amd import _lib
+    lib = _lib.load()
+    B, H, C, O, ks = 2, 264, 32, 64, 3                 # M = 139 392 >= 256 * 512: the default takes the 256x64 tile
+    rng = np.random.default_rng(17)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, H, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((ks, ks, C, O)) * np.sqrt(2.0 / (ks * ks * C))).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    r = gpu_util.bf16_round(rng.standard_normal((B, H, H, O)).astype(np.float32))
+    want = _ref(x, k, b, 1, True, residual=r)
+    outs = {}
+    try:
+        for tile in (0, 64, 261):
+            _lib.check(lib.y3_set_conv_tile(tile))
+            outs[tile] = gpu_util.run_conv(x, k, b, 1, "bf16", leaky=True, residual=r)
+            assert np.all(np.abs(outs[tile] - want) <= 1e-2 * np.maximum(1.0, np.abs(want))), tile
+    finally:
+        lib.y3_set_conv_tile(0)
+    np.testing.assert_array_equal(outs[0], outs[64])
+    np.testing.assert_array_equal(outs[0], outs[261])

@@ -25,6 +25,7 @@
 //   256  conv_igemm_kernel<256,256, 8 waves>   Cout >= 256, few rounds         persistent, register epilogue
 //   192  conv_igemm_kernel<192,256, 8 waves>   same, when it saves a round     persistent, register epilogue
 //   257  conv_igemm_ring_kernel<256,128,RING 3> 65..128 output channels (bf16)  two workgroups per CU
+//   260  conv_igemm_kernel<256,64, 8 waves>    33..64 output channels (bf16)   two workgroups per CU
 //   128 / 64 / 32  conv_igemm_kernel<128,BN>   small layers, fp32 mode         2-3 workgroups per CU
 //   direct  conv_direct_kernel                 Cin = 3 (first layer) when the fused stem is not used
 // Alternatives: 129 (128x256), 258 (256x128, 8 waves), 130/131 (128x128 ring), debug bit 4 (ring for 256/128).
@@ -858,6 +859,12 @@ int launch_igemm(const ConvArgs &a, int n_pad, hipStream_t stream) {
 // 0.80 of a 256x256 one, a 128x128 one 0.55 with two of them resident per CU).
 inline int conv_variant(const y3_conv_desc *d, long M) {
     const int bn = d->out_c > 64 ? 128 : (d->out_c > 32 ? 64 : 32);
+    if (bn == 64 && d->dtype == Y3_BF16) {
+        // 33..64 output channels: 256 pixels x 64 channels on 8 waves, two workgroups per CU (half the tiles, hence
+        // half the per-tile set-up and weight re-reads of the 128x64 tile: -7 % on 3x3 32->64 @304); 261 = ring form
+        if (g_conv_tile == 64 || g_conv_tile == 261) return g_conv_tile;
+        return M >= 256L * 512 ? 260 : 64;
+    }
     if (bn != 128) return bn;
     int tile = g_conv_tile;
     if (tile == 0) {
@@ -1019,6 +1026,8 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
         if (v == 131) return launch_ring<true, 128, 128, 2, 2, 128, 4>(a, d->n_pad, stream);   // 64 KB: 2 per CU, 3 sub-steps ahead
         if (v == 192) return launch_igemm<true, 192, 256, 2, 4, 96>(a, d->n_pad, stream);
         if (v == 128) return launch_igemm<true, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
+        if (v == 260) return launch_igemm<true, 256, 64, 4, 2, 128>(a, d->n_pad, stream);     // 256 pixels x 64 channels, 8 waves
+        if (v == 261) return launch_ring<true, 256, 64, 2, 2, 128, 3>(a, d->n_pad, stream);    // same tile, ring, 4 waves
         if (v == 64) return launch_igemm<true, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
         return launch_igemm<true, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
     }
@@ -1047,6 +1056,8 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     if (v == 257) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 128, 2, 2", t);
     else if (v == 129) snprintf(buf, (size_t)len, "%s<%s, 128, 256, 2, 4", k, t);
     else if (v == 258) snprintf(buf, (size_t)len, "conv_igemm_kernel<%s, 256, 128, 4, 2", t);
+    else if (v == 260) snprintf(buf, (size_t)len, "conv_igemm_kernel<%s, 256, 64, 4, 2", t);
+    else if (v == 261) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 64, 2, 2", t);
     else if (v == 130 || v == 131) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 128, 128, 2, 2", t);
     else if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
     else if (v == 192) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
@@ -1075,7 +1086,7 @@ extern "C" int y3_set_conv_phase(int percent) {
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
-    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 257 || tile == 258, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
+    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 64 || tile == 257 || tile == 258 || tile == 260 || tile == 261, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
     g_conv_tile = tile;
     return Y3_OK;
 }
