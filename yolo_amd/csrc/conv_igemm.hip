@@ -226,6 +226,9 @@ constexpr int CONV_REG_EPILOGUE = 1 << 26;
 #ifndef Y3_RES_AUX
 #define Y3_RES_AUX 0
 #endif
+#ifndef Y3_PIECE_J0
+#define Y3_PIECE_J0 0     // MFMA groups of a k-step that run before the first LDS-DMA piece is issued (4, 8: +1 % slower)
+#endif
 #ifndef Y3_XPF_MAX_ACC
 #define Y3_XPF_MAX_ACC 64  // largest accumulator tile (registers per lane) that gets the cross-tile prefetch
 #endif
@@ -392,6 +395,7 @@ void conv_igemm_kernel(const ConvArgs p) {
     // the MFMAs of the first half of the k-step, and land during the second half.
     constexpr int NP = A_IT + B_IT;
     constexpr int NMF = NI * MI;                 // MFMA groups per 32-deep half step
+    constexpr int J0 = NMF >= 16 ? Y3_PIECE_J0 : 0;
     long toff = 0;
     int tapc = 0;
     auto stage_begin = [&]() {
@@ -485,9 +489,12 @@ void conv_igemm_kernel(const ConvArgs p) {
             for (int j = 0; j < NMF; ++j) {
                 if constexpr (PF) {
                     if (ks == 0) {
-                        // piece q goes before MFMA group floor(q * NMF / NP): q in [ceil(j NP / NMF), ceil((j+1) NP / NMF))
+                        // piece q goes before MFMA group J0 + floor(q * NJ / NP), NJ = NMF - J0: the first J0 groups carry
+                        // no piece (and no scheduling barrier), so that they can start while the later fragment reads
+                        // of this half-step are still in flight
+                        constexpr int NJ = NMF - J0;
 #pragma unroll
-                        for (int q = (j * NP + NMF - 1) / NMF; q < ((j + 1) * NP + NMF - 1) / NMF; ++q) {
+                        for (int q = j < J0 ? NP : ((j - J0) * NP + NJ - 1) / NJ; q < ((j - J0 + 1) * NP + NJ - 1) / NJ; ++q) {
                             if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
                             piece(q, kt + 1, pb ^ 1);
                             if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
