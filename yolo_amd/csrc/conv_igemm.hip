@@ -410,6 +410,8 @@ void conv_igemm_kernel(const ConvArgs p) {
         cin = wrap ? cin - p.Cin : cin;
         tap = wrap ? tap + 1 : tap;
     };
+    // (the uniform branch these two experiment flags put around every piece is worth keeping: compiled out, the
+    // scheduler packs the pieces differently and the network runs 1 % slower)
     const bool skip_a = p.flags & (1 << 29), skip_b = p.flags & (1 << 28);
     auto piece = [&](int q, int kt, int buf) {
         char *base = smem + buf * STAGE + wave * 1024;
