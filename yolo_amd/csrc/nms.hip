@@ -91,18 +91,22 @@ __device__ __forceinline__ unsigned long long make_key(float score, int idx) {
 __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, const int *cand_idx, const int *cand_count,
                                                        const int *class_count, int B, int N, int C, int max_boxes,
                                                        float thr, int *kept_idx, int *kept_rank, int *kept_count,
-                                                       const int *ws, int ws_stride, int small_limit) {
+                                                       const int *ws, int ws_stride, int small_limit, int lds_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *s_list = (int *)smem;                                   // [N] pooled indices of this class
     unsigned char *s_alive = (unsigned char *)(s_list + N);      // [N] LDS-resident suppression state
     __shared__ unsigned long long s_part[2][4];
+    __shared__ f32x4 s_wbox[2][4];
     __shared__ int s_n;
     __shared__ int s_rank[kThreads];
     __shared__ int s_kept[kThreads];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int pair = blockIdx.x; pair < B * C; pair += gridDim.x) {
-        const int b = pair / C, c = pair - b * C;
+    for (int slot = blockIdx.x; slot < B * C; slot += gridDim.x) {
+        // class-major walk: a crowded class is crowded in every image, and b * C + c strided by the grid would hand
+        // all of its images to the same few workgroups (C = 80, grid 256: 16 of them)
+        const int c = slot / B, b = slot - c * B;
+        const int pair = b * C + c;
         int *kidx = kept_idx + (long)pair * max_boxes;
         const int ncls = class_count[pair];                      // wave-uniform
         if (ncls == 0) {
@@ -122,9 +126,22 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
         const int *cl = cand_idx + (long)b * N;
         const int cw = 5 + (c >> 5);
         const unsigned cbit = 1u << (c & 31);
-        if (bucketed) {
-            const int *seg = wsb + kWsHeader + wsb[c];
-            const int nseg = min(ncls, N);
+        // Bucketed pairs whose boxes and keys (24 bytes a candidate) fit the LDS keep them there: a sweep then reads
+        // LDS instead of 20 bytes per candidate from L2, and the winner's box comes from the winning wave, not from
+        // memory (dense scenes: thousands of candidates per class, 51 sweeps each).
+        const int nseg = min(ncls, N);
+        const bool cached = bucketed && (long)nseg * 24 <= lds_bytes;       // block-uniform
+        f32x4 *c_box = (f32x4 *)smem;                                       // [nseg]
+        unsigned long long *c_key = (unsigned long long *)(smem + (long)nseg * 16);   // [nseg], 0 = suppressed
+        const int *seg = bucketed ? wsb + kWsHeader + wsb[c] : nullptr;
+        if (cached) {
+            for (int i = tid; i < nseg; i += kThreads) {
+                const int idx = seg[i];
+                c_box[i] = *(const f32x4 *)(rec + (long)idx * 8);
+                c_key[i] = make_key(rec[(long)idx * 8 + 4], idx);
+            }
+            if (tid == 0) s_n = nseg;
+        } else if (bucketed) {
             for (int i = tid; i < nseg; i += kThreads) { s_list[i] = seg[i]; s_alive[i] = 1; }
             if (tid == 0) s_n = nseg;
         }
@@ -155,15 +172,28 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
         while (kept < max_boxes) {
             // sweep: suppress against the last winner, find the best survivor
             unsigned long long best = 0ull;
-            for (int i = tid; i < n; i += kThreads) {
-                if (!s_alive[i]) continue;
-                const int idx = s_list[i];
-                const f32x4 bx = *(const f32x4 *)(rec + (long)idx * 8);
-                if (win_idx >= 0 && (idx == win_idx || iou_gt(bx, win, thr))) { s_alive[i] = 0; continue; }
-                const unsigned long long key = make_key(rec[(long)idx * 8 + 4], idx);
-                best = key > best ? key : best;
+            f32x4 bbox = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (cached) {
+                for (int i = tid; i < n; i += kThreads) {
+                    const unsigned long long key = c_key[i];
+                    if (key == 0ull) continue;
+                    const f32x4 bx = c_box[i];
+                    if (win_idx >= 0 && ((int)(~(unsigned)key) == win_idx || iou_gt(bx, win, thr))) { c_key[i] = 0ull; continue; }
+                    if (key > best) { best = key; bbox = bx; }
+                }
+            } else {
+                for (int i = tid; i < n; i += kThreads) {
+                    if (!s_alive[i]) continue;
+                    const int idx = s_list[i];
+                    const f32x4 bx = *(const f32x4 *)(rec + (long)idx * 8);
+                    if (win_idx >= 0 && (idx == win_idx || iou_gt(bx, win, thr))) { s_alive[i] = 0; continue; }
+                    const unsigned long long key = make_key(rec[(long)idx * 8 + 4], idx);
+                    best = key > best ? key : best;
+                }
             }
+            const unsigned long long lbest = best;
             best = wave_max_u64(best);
+            if (cached && best != 0ull && lbest == best) s_wbox[kept & 1][wave] = bbox;      // keys are unique: one lane
             if (lane == 0) s_part[kept & 1][wave] = best;
             __syncthreads();
             const unsigned long long p0 = s_part[kept & 1][0], p1 = s_part[kept & 1][1];
@@ -173,7 +203,12 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
             bb = bb > cc ? bb : cc;
             if (bb == 0ull) break;                               // nothing alive (block-uniform)
             win_idx = (int)(~(unsigned)bb);
-            win = *(const f32x4 *)(rec + (long)win_idx * 8);
+            if (cached) {
+                const int ww = bb == p0 ? 0 : (bb == p1 ? 1 : (bb == p2 ? 2 : 3));
+                win = s_wbox[kept & 1][ww];
+            } else {
+                win = *(const f32x4 *)(rec + (long)win_idx * 8);
+            }
             if (tid == 0) { kidx[kept] = win_idx; s_kept[kept] = win_idx; }
             ++kept;
         }
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
             for (int k = 0; k < kept; ++k) {
                 const int kid = s_kept[k];
                 int cnt = 0;
-                for (int i = tid; i < n; i += kThreads) cnt += s_list[i] < kid ? 1 : 0;
+                for (int i = tid; i < n; i += kThreads) cnt += (cached ? seg[i] : s_list[i]) < kid ? 1 : 0;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
                 if (lane == 0 && cnt) atomicAdd(&s_rank[k], cnt);
@@ -446,8 +481,11 @@ static int launch_nms(const float *records, const int32_t *cand_idx, const int32
     Y3_REQUIRE(batch > 0 && boxes_per_image > 0 && num_classes > 0 && num_classes <= 96, Y3_E_INVALID, "nms: bad shape");
     Y3_REQUIRE(max_boxes > 0 && max_boxes <= kThreads, Y3_E_INVALID, "nms: max_boxes %d (1..%d)", max_boxes, kThreads);
     Y3_REQUIRE(aligned16(records), Y3_E_ALIGN, "nms: records not 16-byte aligned");
-    const int lds = (boxes_per_image * 5 + 15) / 16 * 16;
-    Y3_REQUIRE(lds <= 150 * 1024, Y3_E_INVALID, "nms: %d boxes per image exceed the LDS-resident limit (30720)", boxes_per_image);
+    const int lds_scan = (boxes_per_image * 5 + 15) / 16 * 16;
+    Y3_REQUIRE(lds_scan <= 150 * 1024, Y3_E_INVALID, "nms: %d boxes per image exceed the LDS-resident limit (30720)", boxes_per_image);
+    // with a workspace: room for 24-byte cached candidates as well (up to 6144 of them), one workgroup per CU then
+    const int lds_cache = workspace ? (boxes_per_image < 6144 ? boxes_per_image : 6144) * 24 : 0;
+    const int lds = lds_scan > lds_cache ? lds_scan : lds_cache;
     static thread_local int attr_dev = -1, attr_lds = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -476,7 +514,7 @@ static int launch_nms(const float *records, const int32_t *cand_idx, const int32
     if (blocks > pairs) blocks = pairs;
     hipLaunchKernelGGL(nms_kernel, dim3(blocks), dim3(kThreads), lds, stream, records, cand_idx, cand_count,
                        class_count, batch, boxes_per_image, num_classes, max_boxes, iou_threshold, kept_idx, kept_rank, kept_count,
-                       workspace, ws_stride, kBlockMax);
+                       workspace, ws_stride, kBlockMax, lds);
     return y3_check_launch("nms");
 }
 
