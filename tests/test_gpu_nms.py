@@ -106,3 +106,37 @@ def test_nms_multi_class_ties_share_a_box():
     assert m == len(oc) == 3
     np.testing.assert_array_equal(out["classes"][0, :m], oc)
     np.testing.assert_array_equal(out["boxes"][0, :m], ob)
+
+
+def test_nms_crowded_classes_lds_cached_path():
+    """Dense scenes put thousands of boxes in a few classes (BASELINE config 5: three classes of ~5 750 at 608).
+    Pairs of 1 025..6 144 candidates take nms_kernel's LDS-cached sweep; this pins it -- score ties, rank
+    (tf nms_index) and a class just over the cache limit included -- against the oracle and, through run_nms,
+    against the plain y3_nms scan."""
+    rng = np.random.default_rng(77)
+    C, n = 80, 18000
+    sizes = {3: 5776, 40: 1300, 79: 6200, 7: 2048, 12: 900}          # 6200 > 6144: stays on the un-cached scan
+    scenes = []
+    for img in range(2):
+        yx = rng.uniform(0, 560, (n, 2)); hw = rng.uniform(8, 90, (n, 2))
+        boxes = np.concatenate([yx, yx + hw], axis=1).astype(np.float32)
+        dense = np.zeros((n, C), dtype=np.float32)
+        cls = np.concatenate([np.full(k, c) for c, k in sizes.items()])
+        cls = np.concatenate([cls, rng.integers(0, C, n - len(cls))])
+        rng.shuffle(cls)
+        sc = rng.choice(np.linspace(0.05, 1, 400), n) if img == 0 else rng.uniform(0.01, 1, n)
+        dense[np.arange(n), cls] = sc.astype(np.float32)
+        scenes.append((boxes, dense))
+    recs = [gpu_util.records_from_dense(b, d, 0.001) for b, d in scenes]
+    out = gpu_util.run_nms(recs, C, 51, 0.3)
+    for i, (boxes, dense) in enumerate(scenes):
+        ob, os_, oc, orank, opool = odec.select(boxes, dense, 0.001, 0.3, 51, return_index=True)
+        m = int(out["count"][i])
+        assert m == len(oc)
+        np.testing.assert_array_equal(out["classes"][i, :m], oc)
+        np.testing.assert_array_equal(out["boxes"][i, :m], ob)
+        np.testing.assert_array_equal(out["scores"][i, :m], os_)
+        got_pool = np.concatenate([out["kept_idx"][i, c, :out["kept_count"][i, c]] for c in range(C)])
+        got_rank = np.concatenate([out["kept_rank"][i, c, :out["kept_count"][i, c]] for c in range(C)])
+        np.testing.assert_array_equal(got_pool, opool)
+        np.testing.assert_array_equal(got_rank, orank)
