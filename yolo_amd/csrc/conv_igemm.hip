@@ -881,7 +881,7 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
         // 65..128 output channels, bf16, enough tiles for two workgroups per CU: the 256-pixel x 128-channel ring
         // kernel (half the weight re-reads of the 128x128 tile; measured -3..-6 % on the 1x1 256->128 and
         // 3x3 64->128 layers once its occupancy was pinned to two workgroups per CU)
-        if (d->n_pad == 128 && d->dtype == Y3_BF16 && M >= 256L * 512) tile = 257;
+        if (d->n_pad == 128 && d->dtype == Y3_BF16 && M >= 256L * 256) tile = 257;
         if (d->n_pad % 256 == 0) {
             const long cus = 256;
             auto rounds = [&](long bm, long bnn, long per_cu) {
