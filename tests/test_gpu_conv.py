@@ -246,3 +246,27 @@ def test_conv_cout64_tile_variants_agree():
         lib.y3_set_conv_tile(0)
     np.testing.assert_array_equal(outs[0], outs[64])
     np.testing.assert_array_equal(outs[0], outs[261])
+
+
+@pytest.mark.parametrize("case", ["ring_ups", "ring_1x1_res", "head_f32_256tile"])
+def test_conv_bench_scale_defaults(case):
+    """Kernel choices that only engage at bench-scale pixel counts (M >= 65 536), against the oracle: the
+    256x128 ring tile with the 2x2 upsampling store (LDS epilogue inside the ring kernel), the same tile with
+    a shortcut (register epilogue, early residual loads), and an fp32-output head on the 256-row tiles."""
+    rng = np.random.default_rng(23)
+    if case == "ring_ups":
+        B, H, C, O, ks, kw = 12, 76, 256, 128, 1, dict(ups=True, out_pad=(0, 256))
+    elif case == "ring_1x1_res":
+        B, H, C, O, ks, kw = 12, 76, 256, 128, 1, dict()
+    else:
+        B, H, C, O, ks, kw = 12, 76, 256, 255, 1, dict(out_f32=True, leaky=False)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, H, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((ks, ks, C, O)) * np.sqrt(2.0 / (ks * ks * C))).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    r = gpu_util.bf16_round(rng.standard_normal((B, H, H, O)).astype(np.float32)) if case == "ring_1x1_res" else None
+    leaky = kw.pop("leaky", True)
+    got = gpu_util.run_conv(x, k, b, 1, "bf16", leaky=leaky, residual=r, **kw)
+    want = _ref(x, k, b, 1, leaky, residual=r, ups=kw.get("ups", False))
+    assert got.shape == want.shape
+    tol = (2e-3 if case == "head_f32_256tile" else 1e-2) * np.maximum(1.0, np.abs(want))
+    assert np.all(np.abs(got - want) <= tol)
