@@ -134,6 +134,13 @@ def test_full_size_properties_608_bf16():
         assert torch.equal(a, b)
         assert torch.equal(a[0], a[9])
     assert [tuple(h.shape) for h in heads] == [(16, 19, 19, 255), (16, 38, 38, 255), (16, 76, 76, 255)]
+    # batch 16 picks the big tiles (256x256, 192x256, 256x128 ring, 256x64), batch 1 the small ones: every variant sums
+    # k in the same order, so the same image gives the same bits -- and batch 1 is checked against the oracle
+    one = [h.clone() for h in nodes(xt[:1])]
+    ref = od.forward(layers, oi, params, x[:1])
+    for a, o, r in zip(heads, one, ref):
+        assert torch.equal(a[:1], o)
+        assert np.abs(o.cpu().numpy() - r).max() / np.abs(r).max() <= 2e-2
     anchors = inference.read_anchors(config.anchors_path)
     det = inference.predict_batch(heads, anchors, 80, (608, 608), (608, 608))
     m0 = _check_nms_exact(det, 0, config.score_threshold)
