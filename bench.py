@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24, help="timed images of the CPU baseline (plus 1 warm-up)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--splitk", action="store_true", help="split launches with few output tiles over k (small-batch latency mode)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (yolo_amd.graph.GraphedDetector): the serving mode at small "
                          "batch; per-kernel events, hence the roofline object, are not available in it")
@@ -107,7 +108,7 @@ def main():
     config.score_threshold = args.score_threshold
     B, S = args.batch, args.size
 
-    nodes = build_model.yolo(None, False, cfg, config.num_classes, dtype=args.dtype, device=dev)
+    nodes = build_model.yolo(None, False, cfg, config.num_classes, dtype=args.dtype, device=dev, splitk=args.splitk)
     net = nodes.net
     net.set_params(dw.random_params(net.layers, seed=0))          # every rank: same seeded weights
     lo, hi = sharding.shard_range(world * B, rank, world)         # this rank's images of the global batch

@@ -75,6 +75,17 @@ int y3_conv_weight_layout(y3_conv_desc *desc);
 int y3_conv2d_fused(const y3_conv_desc *desc, const void *in, const void *w, const float *bias,
                     const void *residual, void *out, const void *zeros, void *stream);
 
+/* Split-K form of the same convolution for launches with few output tiles and a long k (small batches: the
+ * reference runs one image per step, inference.py:243): `splits` workgroups per tile write fp32 partial sums to
+ * the caller's workspace, a second kernel adds them in a fixed order (deterministic) and applies bias,
+ * activation, shortcut and the store.  y3_conv_splitk_plan (host only) says how many splits this descriptor
+ * gets (1 = none: y3_conv2d_splitk then is y3_conv2d_fused) and how large the workspace must be.  Results equal
+ * y3_conv2d_fused's up to fp32 summation order. */
+int y3_conv_splitk_plan(const y3_conv_desc *desc, int32_t *splits, int64_t *workspace_bytes);
+int y3_conv2d_splitk(const y3_conv_desc *desc, const void *in, const void *w, const float *bias,
+                     const void *residual, void *out, const void *zeros, void *workspace,
+                     int64_t workspace_bytes, void *stream);
+
 /* Fused network stem, bf16 mode: the first three convolutions of Darknet-53 in one launch, the
  * 32-channel full-resolution tensor between the first two never leaving LDS:
  *   conv A 3x3 s1 3->c0 on the fp32 NHWC image, conv B 3x3 s2 c0->c1, optional conv C 1x1 c1->c2

@@ -389,3 +389,33 @@ def _graphed_vs_eager(GraphedDetector, nodes, anchors):
         bx, sc, cl = gd.image(1)
         assert bx.shape == (counts[1], 4) and cl.dtype == np.int32
     assert found > 0 and gd.graph is not None
+
+
+@pytest.mark.parametrize("dtype,size", [("fp32", 224), ("bf16", 608)])
+def test_splitk_small_batch_mode(dtype, size):
+    """Network(splitk=True): at batch 1 the launches with few output tiles and a long k are split over k
+    (y3_conv2d_splitk: fp32 partial sums, fixed-order finish).  Same tolerance against the oracle as the
+    un-split path, results reproducible run to run, and close to the un-split result."""
+    layers, oi = od.parse_layers(config.yolov3_cfg_path, 80)
+    params = dw.random_params(layers, seed=21)
+    x = np.random.default_rng(21).random((1, size, size, 3), dtype=np.float32)
+    xt = torch.from_numpy(x).cuda()
+    outs = {}
+    for sk in (True, False):
+        net = build_model.Network(config.yolov3_cfg_path, 80, dtype=dtype, splitk=sk)
+        net.set_params(params)
+        plan = net.plan_for(1, size, size).plan
+        n_split = sum(1 for op in plan.ops if op.get("splits", 1) > 1)
+        assert (n_split > 10) == sk
+        a = [h.clone() for h in net(xt)]
+        b = [h.clone() for h in net(xt)]
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)                 # deterministic: partial sums are added in a fixed order
+        outs[sk] = [h.cpu().numpy() for h in a]
+    ref = od.forward(layers, oi, params, x)
+    for s_, u_, r in zip(outs[True], outs[False], ref):
+        if dtype == "fp32":
+            assert np.abs(s_ - r).max() <= 1e-3 and np.abs(s_ - u_).max() <= 1e-4
+        else:
+            assert np.abs(s_ - r).max() / np.abs(r).max() <= 2e-2
+            assert np.abs(s_ - u_).max() / np.abs(r).max() <= 1e-2

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-stem", action="store_true")
+    ap.add_argument("--splitk", action="store_true")
     ap.add_argument("--phase", type=int, default=-1, help="de-phasing offset in percent of a tile period (0 = off)")
     a = ap.parse_args()
     cfg = config.yolov3_tiny_cfg_path if a.model == "yolov3-tiny" else config.yolov3_cfg_path
@@ -30,7 +31,7 @@ def main():
     _lib.check(_lib.load().y3_set_conv_tile(a.tile))
     if a.phase >= 0:
         _lib.check(_lib.load().y3_set_conv_phase(a.phase))
-    net = build_model.Network(cfg, 80, dtype=a.dtype, stem=not a.no_stem)
+    net = build_model.Network(cfg, 80, dtype=a.dtype, stem=not a.no_stem, splitk=a.splitk)
     net.set_params(dw.random_params(net.layers, seed=0))
     x = torch.rand((a.batch, a.size, a.size, 3), device="cuda")
     for _ in range(2):

@@ -62,7 +62,34 @@ class _CompiledPlan(object):
     def __init__(self, net, plan):
         self.plan = plan
         self.arena = torch.empty(max(plan.arena_bytes, 256), dtype=torch.uint8, device=net.device)
+        self._splitk_ws = None          # one fp32 partial-sum buffer shared by the plan's split-K launches (they run in order)
+        need = 0
+        if net.splitk:
+            for op in plan.ops:
+                if op["kind"] == "conv":
+                    need = max(need, self._splitk_bytes(net, op))
+        if need:
+            self._splitk_ws = torch.empty(need, dtype=torch.uint8, device=net.device)
         self.launchers = [self._prepare(net, op) for op in plan.ops]
+
+    def splitk_workspace(self, net, nbytes):
+        assert self._splitk_ws is not None and self._splitk_ws.numel() >= nbytes
+        return self._splitk_ws
+
+    def _splitk_bytes(self, net, op):
+        """Workspace y3_conv_splitk_plan asks for this conv op (0 = not split).  Needs the packed layout only."""
+        lib = _lib.load()
+        w, bias, fam, k_pad, n_pad = net._packed[op["layer"]]
+        d = _lib.ConvDesc()
+        d.dtype, d.batch = _dtype_code(self.plan.dtype), self.plan.batch
+        d.in_h, d.in_w = op["in_hw"]
+        d.in_c = op["in_c"]
+        d.out_h, d.out_w = op["out_hw"]
+        d.out_c, d.ksize, d.stride, d.k_pad, d.n_pad = op["out_c"], op["ksize"], op["stride"], k_pad, n_pad
+        d.flags = _lib.CONV_IN_F32 if op["in_f32"] else 0
+        splits, ws_bytes = ctypes.c_int32(1), ctypes.c_int64(0)
+        _lib.check(lib.y3_conv_splitk_plan(ctypes.byref(d), ctypes.byref(splits), ctypes.byref(ws_bytes)))
+        return int(ws_bytes.value) if splits.value > 1 else 0
 
     def _ptr(self, ref, es):
         """-> (kind, base_offset_bytes)"""
@@ -119,6 +146,17 @@ class _CompiledPlan(object):
             r = resolver(op["res"]) if op["res"] is not None else (lambda env: None)
             wp, bp, zp = w.data_ptr(), bias.data_ptr(), net._zeros.data_ptr()
             fn = lib.y3_conv2d_fused
+            if net.splitk:              # small-batch mode: launches with few tiles and a long k are split over k
+                splits, ws_bytes = ctypes.c_int32(1), ctypes.c_int64(0)
+                _lib.check(lib.y3_conv_splitk_plan(dref, ctypes.byref(splits), ctypes.byref(ws_bytes)))
+                if splits.value > 1:
+                    op["splits"] = splits.value
+                    ws = self.splitk_workspace(net, ws_bytes.value)
+                    wsp, wsn, fk = ws.data_ptr(), ws.numel(), lib.y3_conv2d_splitk
+
+                    def launch_split(env, _keep=(d, w, bias, ws)):
+                        return fk(dref, x(env), wp, bp, r(env), y(env), zp, wsp, wsn, env["stream"])
+                    return launch_split
 
             def launch(env, _keep=(d, w, bias)):
                 return fn(dref, x(env), wp, bp, r(env), y(env), zp, env["stream"])
@@ -180,7 +218,7 @@ class Network(object):
     """The compiled detector: cfg layers + packed device weights + cached launch plans."""
 
     def __init__(self, config_path, num_classes, dtype=None, device=None, fuse=True, pad_input=False, stem=True,
-                 snake=None):
+                 snake=None, splitk=False):
         self.config_path = config_path
         self.num_classes = num_classes
         self.dtype = dtype or config.compute_dtype
@@ -193,6 +231,9 @@ class Network(object):
         self.stem = stem            # fuse Darknet-53's first three convolutions into one launch (bf16 mode)
         # consecutive convolutions walk their tiles in opposite directions (cache reuse); YOLO_AMD_SNAKE=0 for A/B runs
         self.snake = (os.environ.get("YOLO_AMD_SNAKE", "1") != "0") if snake is None else bool(snake)
+        # split-K for launches with few output tiles (small batches: latency mode).  Off by default: split sums are
+        # added in another order, so results are no longer bit-identical across batch sizes / chunking.
+        self.splitk = bool(splitk)
         self.layers, self.out_index = planner.parse_cfg(config_path, num_classes, config.num_anchors_per_scale)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.params = None
@@ -312,13 +353,13 @@ class OutputNodes(list):
     __call__ = run
 
 
-def yolo(input_images, is_training, config_path, num_classes, dtype=None, device=None):
+def yolo(input_images, is_training, config_path, num_classes, dtype=None, device=None, splitk=False):
     """Builds the network described by a Darknet cfg (reference build_model.py:36-270).
     input_images is accepted for signature parity and may be None (the reference passes a
     placeholder); is_training must be False (inference path only)."""
     if is_training:
         raise ValueError("yolo_amd implements the inference path only: is_training must be False")
-    net = Network(config_path, num_classes, dtype=dtype, device=device)
+    net = Network(config_path, num_classes, dtype=dtype, device=device, splitk=splitk)
     _NETWORKS.append(net)
     return OutputNodes(net)
 

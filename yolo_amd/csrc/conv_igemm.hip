@@ -61,6 +61,8 @@ struct ConvArgs {
     int total_tiles;
     int delay_from;                    // persistent workgroups with blockIdx.x >= delay_from start delay_ticks late
     unsigned delay_ticks;              // in s_memrealtime ticks (100 MHz)
+    int splits, nk_split;              // split-K: a tile's k-steps are dealt to `splits` workgroups, nk_split each
+    long slice_elems;                  // ... which write fp32 partial sums to out + split * slice_elems
 };
 
 // Output row gm -> byte offset of its window's first input element and the 9-bit (1-bit for 1x1)
@@ -101,11 +103,13 @@ __device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+constexpr int CONV_NO_BIAS = 1 << 24;    // internal flag: split-K partial sums carry no bias
+
 // Epilogue shared by the convolution kernels: accumulators -> LDS (fp32) -> bias, leaky, residual ->
 // NHWC rows with 16-byte stores, EP_ROWS tile rows per pass.
 template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, int MI, int NI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI][MI], char *smem, int m0, int n0,
-                                              int tid, int wm, int wn) {
+                                              int tid, int wm, int wn, long out_shift = 0) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int ES = BF16 ? 2 : 4;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
@@ -156,8 +160,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
             if (gm >= p.M || n >= p.Cout8) continue;
             f32x4 v0 = *(const f32x4 *)(Cs + row * CS_LD + ch * 8);
             f32x4 v1 = *(const f32x4 *)(Cs + row * CS_LD + ch * 8 + 4);
-            v0 += *(const f32x4 *)(p.bias + n);
-            v1 += *(const f32x4 *)(p.bias + n + 4);
+            if (!(p.flags & CONV_NO_BIAS)) {         // split-K partial sums: the bias is added once, by the finishing kernel
+                v0 += *(const f32x4 *)(p.bias + n);
+                v1 += *(const f32x4 *)(p.bias + n + 4);
+            }
             if (leaky) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v0[j] = leaky01(v0[j]); v1[j] = leaky01(v1[j]); }
@@ -193,7 +199,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
             for (int rpt = 0; rpt < reps; ++rpt) {
                 const long pix = opix + (rpt & 1) + (rpt >> 1) * row2;
                 if (out_f32) {
-                    float *op = (float *)p.out + pix * p.out_ld + n;
+                    float *op = (float *)p.out + out_shift + pix * p.out_ld + n;
                     *(f32x4 *)op = v0;
                     *(f32x4 *)(op + 4) = v1;
                 } else {
@@ -371,8 +377,14 @@ void conv_igemm_kernel(const ConvArgs p) {
     unsigned a_mask[A_IT];
     long w_off[B_IT];
     int tap = 0, cin = 0;
+    int kt0 = 0;                                 // first k-step of this workgroup's share of the tile (split-K)
     auto tile_setup = [&](int tile, int &tm0, int &tn0) {
-        const int bid = xcd_remap(tile, p.total_tiles, p.flags & Y3_CONV_REVERSE);
+        int bid = xcd_remap(tile, p.total_tiles, p.flags & Y3_CONV_REVERSE);
+        if (p.splits > 1) {                      // uniform; the splits of one tile are neighbours
+            const int sp = bid % p.splits;
+            bid /= p.splits;
+            kt0 = sp * p.nk_split;
+        }
         const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
         tm0 = mt * BM;
         tn0 = nt * BN;
@@ -387,6 +399,11 @@ void conv_igemm_kernel(const ConvArgs p) {
         for (int i = 0; i < B_IT; ++i) w_off[i] = ((long)(tn0 + lrow + LROWS * i) * p.Kpad + kc) * ES;
         tap = tap0;
         cin = cin0;
+        if (kt0 != 0) {
+            const int k = kc + kt0 * BKE;
+            tap = k / p.Cin;
+            cin = k - tap * p.Cin;
+        }
     };
 
     // One k-step of loads is NP = A_IT + B_IT LDS-DMA pieces (1 KiB per wave each).  An LDS-DMA
@@ -443,7 +460,7 @@ void conv_igemm_kernel(const ConvArgs p) {
     stage_begin();
     if (!primed) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) piece(q, 0, pb);       // free: every wave is past the barrier of the last k-step
+        for (int q = 0; q < NP; ++q) piece(q, kt0, pb);     // free: every wave is past the barrier of the last k-step
     }
     const int m0 = m0n, n0 = n0n;
 
@@ -461,7 +478,8 @@ void conv_igemm_kernel(const ConvArgs p) {
     const int frow = lane & 15;
     const int fsw = (lane >> 1) & 7;
     const int fq = lane >> 4;
-    const int nk = p.Kpad / BKE;
+    const int nk_all = p.Kpad / BKE;
+    const int nk = p.splits > 1 ? min(nk_all, kt0 + p.nk_split) : nk_all;     // one past this workgroup's last k-step
 
     // residual pieces the last k-step fetches ahead of the epilogue (register epilogue only)
     constexpr int RES_EARLY = (BF16 && NI % 2 == 0 && MI * NI * 4 <= 96) ? (MI * (NI / 2) * Y3_RES_EARLY_16THS) / 16 : 0;
@@ -517,7 +535,7 @@ void conv_igemm_kernel(const ConvArgs p) {
         pb ^= 1;
     };
 
-    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, [] {});
+    for (int kt = kt0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, [] {});
     u32x4 rv[MI][NI % 2 == 0 ? NI / 2 : 1];
     auto res_early = [&] {
         if constexpr (RES_EARLY > 0) {
@@ -528,7 +546,7 @@ void conv_igemm_kernel(const ConvArgs p) {
         }
     };
     const int next_tile = tile + (int)gridDim.x;
-    primed = XPF_OK && reg_epi && next_tile < p.total_tiles && !(p.flags & ((1 << 27) | (1 << 25)));
+    primed = XPF_OK && reg_epi && p.splits <= 1 && next_tile < p.total_tiles && !(p.flags & ((1 << 27) | (1 << 25)));
     if (primed) {
         kstep(-1, std::true_type{}, [&] {        // "k-step kt + 1" of the prefetch = k-step 0 of the next tile
             res_early();
@@ -556,7 +574,8 @@ void conv_igemm_kernel(const ConvArgs p) {
             continue;
         }
     }
-    conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI>(p, acc, smem, m0, n0, tid, wm, wn);
+    conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI>(p, acc, smem, m0, n0, tid, wm, wn,
+                                                                   p.splits > 1 ? (long)(kt0 / p.nk_split) * p.slice_elems : 0L);
     __syncthreads();                             // the LDS epilogue's staging area overlaps the pipeline buffers
     }
 }
@@ -803,7 +822,7 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
         attr_dev = dev;
     }
     const int m_tiles = (a.M + BM - 1) / BM;
-    const long nblk = (long)m_tiles * a.n_tiles;
+    const long nblk = (long)m_tiles * a.n_tiles * (a.splits > 1 ? a.splits : 1);
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv: grid of %ld blocks", nblk); return Y3_E_INVALID; }
     a.total_tiles = (int)nblk;
     // persistent grid: as many workgroups as stay resident (LDS-limited), each walking several tiles
@@ -933,9 +952,10 @@ extern "C" int y3_conv_weight_layout(y3_conv_desc *d) {
     return 0;
 }
 
-extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void *w, const float *bias,
-                               const void *residual, void *out, const void *zeros, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// splits > 1: the launch writes `splits` fp32 partial sums per output to `workspace` (no bias, activation,
+// shortcut or upsampling: conv_splitk_finish_kernel applies those once).
+static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, const float *bias,
+                       const void *residual, void *out, const void *zeros, hipStream_t stream, float *workspace, int splits) {
     Y3_REQUIRE(d && in && w && bias && out && zeros, Y3_E_INVALID, "conv: null pointer argument");
     y3_conv_desc chk = *d;
     const int family = y3_conv_weight_layout(&chk);
@@ -1009,10 +1029,20 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     a.sub_tap = (bke / 2) / d->in_c;
     a.sub_cin = (bke / 2) % d->in_c;
     int v = conv_variant(d, M);
+    a.splits = 1; a.nk_split = 0; a.slice_elems = 0;
+    if (splits > 1) {
+        const int nk = d->k_pad / bke;
+        a.splits = splits;
+        a.nk_split = (nk + splits - 1) / splits;
+        a.slice_elems = M * (long)d->n_pad;
+        a.out = (char *)workspace; a.out_ld = d->n_pad; a.Cout8 = d->n_pad; a.res = nullptr;
+        a.flags = (d->flags & (Y3_CONV_IN_F32 | Y3_CONV_REVERSE)) | Y3_CONV_OUT_F32 | CONV_NO_BIAS;
+        v = bn_for(d->out_c);                   // the 128-row tiles (conv_splitk_splits only splits those)
+    }
     {   // register epilogue: bf16 -> bf16 without upsampling, tensors within a 4 GiB buffer descriptor
         const long ob = M * (long)d->out_ld * 2, rb = M * (long)d->res_ld * 2;
         a.out_bytes = a.res_bytes = 0;
-        if (bf16 && !out_f32 && !(d->flags & Y3_CONV_UPS2X) && ob < 0xffff0000L && rb < 0xffff0000L && !(g_conv_debug & 64)) {
+        if (splits <= 1 && bf16 && !out_f32 && !(d->flags & Y3_CONV_UPS2X) && ob < 0xffff0000L && rb < 0xffff0000L && !(g_conv_debug & 64)) {
             a.flags |= CONV_REG_EPILOGUE;
             a.out_bytes = (unsigned)ob;
             a.res_bytes = (unsigned)rb;
@@ -1046,6 +1076,139 @@ extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void
     if (v == 128) return launch_igemm<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
     if (v == 64) return launch_igemm<false, 128, 64, 2, 2, 128>(a, d->n_pad, stream);
     return launch_igemm<false, 128, 32, 4, 1, 128>(a, d->n_pad, stream);
+}
+
+extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void *w, const float *bias,
+                               const void *residual, void *out, const void *zeros, void *stream) {
+    return conv_launch(d, in, w, bias, residual, out, zeros, (hipStream_t)stream, nullptr, 1);
+}
+
+// ---- split-K: small launches (few output tiles, long k) --------------------------------------------------------
+// At batch 1 a 19x19 layer is 24 tiles of 72 k-steps: 24 busy CUs, 50 us.  Split over k, `splits` workgroups per
+// tile write fp32 partial sums to a caller-owned workspace [splits][M][n_pad]; conv_splitk_finish_kernel adds
+// them in a fixed order (deterministic), then bias, leaky-ReLU, shortcut, store (2x2 when upsampling).
+namespace {
+
+int conv_splitk_splits(const y3_conv_desc *d) {
+    y3_conv_desc chk = *d;
+    if (y3_conv_weight_layout(&chk) != 0) return 1;                  // direct-convolution family
+    const long M = (long)d->batch * d->out_h * d->out_w;
+    const int bn = bn_for(d->out_c);
+    const long tiles = ((M + 127) / 128) * (d->n_pad / bn);
+    const int nk = d->k_pad / (d->dtype == Y3_BF16 ? 64 : 32);
+    if (tiles >= 160 || nk < 8) return 1;                            // enough workgroups already, or nothing to split
+    // Measured model (batch 1, 608): an un-split tile takes nk * t_step; split s ways it takes (nk / s) * t_step
+    // + the partial sums' round trip through the workspace (s * M * n_pad * 8 bytes at ~3 TB/s) + ~6 us for the
+    // second launch.  Take the best s; split only if that wins by 20 %.
+    const double t_step = d->dtype == Y3_BF16 ? 0.76 : 1.8;          // us per k-step of a 128-row tile
+    const double a = nk * t_step, b = (double)M * d->n_pad * 8.0 / 3.0e6;
+    int best = 1;
+    double t_best = a * 0.8;
+    for (int s = 2; s <= 16 && s <= nk / 4 && tiles * s <= 1024; ++s) {
+        const int per = (nk + s - 1) / s;
+        if ((nk + per - 1) / per != s) continue;                     // would leave an empty split
+        const double t = per * t_step + b * s + 6.0;
+        if (t < t_best) { t_best = t; best = s; }
+    }
+    return best;
+}
+
+struct FinishArgs {
+    const float *ws, *bias;
+    const char *res;
+    char *out;
+    long M, slice_elems;
+    int splits, n_pad, cout8, out_ld, res_ld, Ho, Wo, flags, bf16;
+};
+
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const FinishArgs p) {
+    const int nch = p.cout8 / 8;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= p.M * nch) return;
+    const long gm = q / nch;
+    const int n = (int)(q - gm * nch) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    for (int s = 0; s < p.splits; ++s) {                             // fixed order: deterministic
+        const float *w = p.ws + s * p.slice_elems + gm * p.n_pad + n;
+        const f32x4 a = *(const f32x4 *)w, b = *(const f32x4 *)(w + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] += p.bias[n + j];
+        if (p.flags & Y3_CONV_LEAKY) v[j] = leaky01(v[j]);
+    }
+    if (p.flags & Y3_CONV_RESIDUAL) {
+        if (p.bf16) {
+            const u32x4 r = *(const u32x4 *)(p.res + (gm * p.res_ld + n) * 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] += bf16_to_f32(r[j] & 0xffff); v[2 * j + 1] += bf16_to_f32(r[j] >> 16); }
+        } else {
+            const float *r = (const float *)p.res + gm * p.res_ld + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
+        }
+    }
+    const bool ups = p.flags & Y3_CONV_UPS2X;
+    long opix = gm, row2 = 0;
+    if (ups) {
+        const long hw = (long)p.Ho * p.Wo;
+        const long b = gm / hw, r = gm - b * hw;
+        const long ho = r / p.Wo, wo = r - ho * p.Wo;
+        row2 = 2L * p.Wo;
+        opix = (b * 2 * p.Ho + 2 * ho) * row2 + 2 * wo;
+    }
+    const bool out_f32 = !p.bf16 || (p.flags & Y3_CONV_OUT_F32);
+    for (int rpt = 0; rpt < (ups ? 4 : 1); ++rpt) {
+        const long pix = opix + (rpt & 1) + (rpt >> 1) * row2;
+        if (out_f32) {
+            float *op = (float *)p.out + pix * p.out_ld + n;
+            *(f32x4 *)op = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4 *)(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+            *(u32x4 *)(p.out + (pix * p.out_ld + n) * 2) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int y3_conv_splitk_plan(const y3_conv_desc *d, int32_t *splits, int64_t *workspace_bytes) {
+    Y3_REQUIRE(d && splits && workspace_bytes, Y3_E_INVALID, "conv_splitk_plan: null pointer argument");
+    const int s = conv_splitk_splits(d);
+    *splits = s;
+    *workspace_bytes = s > 1 ? (int64_t)s * d->batch * d->out_h * d->out_w * d->n_pad * 4 : 0;
+    return Y3_OK;
+}
+
+extern "C" int y3_conv2d_splitk(const y3_conv_desc *d, const void *in, const void *w, const float *bias,
+                                const void *residual, void *out, const void *zeros, void *workspace,
+                                int64_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    Y3_REQUIRE(d != nullptr, Y3_E_INVALID, "conv: null descriptor");
+    const int s = conv_splitk_splits(d);
+    if (s <= 1) return conv_launch(d, in, w, bias, residual, out, zeros, stream, nullptr, 1);
+    const long M = (long)d->batch * d->out_h * d->out_w;
+    Y3_REQUIRE(workspace && workspace_bytes >= (int64_t)s * M * d->n_pad * 4, Y3_E_INVALID,
+               "conv_splitk: workspace of %ld bytes, %ld needed", (long)workspace_bytes, (long)s * M * d->n_pad * 4);
+    Y3_REQUIRE(aligned16(workspace), Y3_E_ALIGN, "conv_splitk: workspace not 16-byte aligned");
+    const int rc = conv_launch(d, in, w, bias, residual, out, zeros, stream, (float *)workspace, s);
+    if (rc) return rc;
+    const bool bf16 = d->dtype == Y3_BF16;
+    FinishArgs f;
+    f.ws = (const float *)workspace; f.bias = bias; f.res = (const char *)residual; f.out = (char *)out;
+    f.M = M; f.slice_elems = M * (long)d->n_pad; f.splits = s; f.n_pad = d->n_pad;
+    f.cout8 = (d->out_c + 7) / 8 * 8; f.out_ld = d->out_ld; f.res_ld = d->res_ld;
+    f.Ho = d->out_h; f.Wo = d->out_w; f.flags = d->flags; f.bf16 = bf16 ? 1 : 0;
+    const long work = M * (f.cout8 / 8);
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, f);
+    return y3_check_launch("conv_splitk_finish");
 }
 
 // Which kernel a descriptor runs on, as rocprof will name it (for benches and profiles).
