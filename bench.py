@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24, help="timed images of the CPU baseline (plus 1 warm-up)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="timed steps that carry HIP events around the dominant kernel's launches: every Nth (an event "
+                         "pair costs ~3 us of stream time; 25 pairs on every step slowed the measured step by 1.6 %%)")
     ap.add_argument("--splitk", action="store_true", help="split launches with few output tiles over k (small-batch latency mode)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (yolo_amd.graph.GraphedDetector): the serving mode at small "
@@ -153,8 +156,8 @@ def main():
     torch.cuda.synchronize()
     traces = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr = None if args.no_kernel_events else []
+    for i in range(args.steps):
+        tr = [] if (not args.no_kernel_events and i % max(args.event_every, 1) == 0) else None
         det = step(tr, only_dom)
         if tr is not None:
             traces.append(tr)
@@ -211,7 +214,8 @@ def main():
                                "kernel": dom + ">", "launches_per_step": dom_n // len(traces),
                                "avg_launch_ms": round(dom_ms / dom_n, 4),
                                "avg_gflop_per_launch": round(dom_flops / dom_n / 1e9, 3),
-                               "share_of_step": round(dom_ms / len(traces) / (1e3 * elapsed / args.steps), 3)}
+                               "share_of_step": round(dom_ms / len(traces) / (1e3 * elapsed / args.steps), 3),
+                               "timed_steps_with_events": len(traces)}
             try:            # HBM bytes per launch of that kernel, from the committed PMC passes (profiles/)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
                 for name, byt in tj["hbm_bytes_per_launch"].items():
