@@ -23,7 +23,7 @@ def to_dev(x, dtype):
 
 
 def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=False, out_f32=False, in_f32=False,
-             in_pad=(0, 0), out_pad=(0, 0)):
+             in_pad=(0, 0), out_pad=(0, 0), splitk=False, info=None):
     """x NHWC fp32 numpy; kernel HWIO; returns the NHWC fp32 numpy output.  in_pad/out_pad =
     (channels before, channels after) embed the tensor in a wider buffer (route slices)."""
     lib = _lib.load()
@@ -57,9 +57,19 @@ def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=Fals
                | (_lib.CONV_UPS2X if ups else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_IN_F32 if in_f32 else 0))
     es_in = xin.element_size()
     es_out = out.element_size()
-    rc = lib.y3_conv2d_fused(ctypes.byref(d), xin.data_ptr() + in_pad[0] * es_in, wt.data_ptr(), bt.data_ptr(),
-                             res_t.data_ptr() if res_t is not None else None,
-                             out.data_ptr() + out_pad[0] * es_out, zeros.data_ptr(), stream())
+    if splitk:          # y3_conv2d_splitk with the workspace its plan asks for (splits == 1: same as y3_conv2d_fused)
+        splits, ws_bytes = ctypes.c_int32(1), ctypes.c_int64(0)
+        _lib.check(lib.y3_conv_splitk_plan(ctypes.byref(d), ctypes.byref(splits), ctypes.byref(ws_bytes)))
+        ws = torch.full((max(int(ws_bytes.value), 16),), 0x7f, dtype=torch.uint8, device="cuda")
+        if info is not None:
+            info["splits"] = int(splits.value)
+        rc = lib.y3_conv2d_splitk(ctypes.byref(d), xin.data_ptr() + in_pad[0] * es_in, wt.data_ptr(), bt.data_ptr(),
+                                  res_t.data_ptr() if res_t is not None else None,
+                                  out.data_ptr() + out_pad[0] * es_out, zeros.data_ptr(), ws.data_ptr(), ws.numel(), stream())
+    else:
+        rc = lib.y3_conv2d_fused(ctypes.byref(d), xin.data_ptr() + in_pad[0] * es_in, wt.data_ptr(), bt.data_ptr(),
+                                 res_t.data_ptr() if res_t is not None else None,
+                                 out.data_ptr() + out_pad[0] * es_out, zeros.data_ptr(), stream())
     _lib.check(rc)
     torch.cuda.synchronize()
     full = out.float().cpu().numpy()

@@ -270,3 +270,48 @@ def test_conv_bench_scale_defaults(case):
     assert got.shape == want.shape
     tol = (2e-3 if case == "head_f32_256tile" else 1e-2) * np.maximum(1.0, np.abs(want))
     assert np.all(np.abs(got - want) <= tol)
+
+
+def test_conv_fuzz_shapes():
+    """Seeded sweep over odd shapes against the oracle: sizes that are not tile multiples, channel counts that are
+    not multiples of 16 / 32, both strides, both kernel sizes, shortcut / upsample / fp32-out variants, both dtypes,
+    with and without split-K."""
+    from yolo_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(4242)
+    n_cases = n_split = 0
+    for it in range(36):
+        dtype = "bf16" if it % 3 else "fp32"
+        ks = int(rng.choice([1, 3]))
+        stride = int(rng.choice([1, 2])) if ks == 3 else 1
+        H = int(rng.integers(5, 41))
+        if stride == 2 and H % 2:
+            H += 1
+        B = int(rng.integers(1, 5))
+        C = int(rng.choice([8, 16, 24, 32, 40, 64, 96, 128, 136]))
+        O = int(rng.choice([8, 18, 32, 33, 64, 75, 128, 130, 255, 256, 264]))
+        if it >= 28:                                # long k, few pixels: the shapes split-K is for
+            ks, C, H, B = 3, int(rng.choice([256, 512, 1024])), int(rng.integers(9, 20)), 1
+            if stride == 2 and H % 2:
+                H += 1
+        mode = int(rng.integers(0, 4))              # 0 plain, 1 shortcut, 2 upsample, 3 fp32 out (linear)
+        x = rng.standard_normal((B, H, H, C)).astype(np.float32)
+        k = (rng.standard_normal((ks, ks, C, O)) * np.sqrt(2.0 / (ks * ks * C))).astype(np.float32)
+        b = rng.standard_normal(O).astype(np.float32)
+        leaky = mode != 3
+        want_shape = _ref(x[:1], k, b, stride, leaky).shape[1:]
+        r = rng.standard_normal((B,) + want_shape).astype(np.float32) if mode == 1 else None
+        if dtype == "bf16":
+            x, k = gpu_util.bf16_round(x), gpu_util.bf16_round(k)
+            r = gpu_util.bf16_round(r) if r is not None else None
+        kw = dict(ups=True) if mode == 2 else (dict(out_f32=True) if mode == 3 else {})
+        want = _ref(x, k, b, stride, leaky, residual=r, ups=(mode == 2))
+        tol = 1e-3 if dtype == "fp32" else (2e-3 if mode == 3 else 1e-2) * np.maximum(1.0, np.abs(want))
+        for sk in (False, True):
+            info = {}
+            got = gpu_util.run_conv(x, k, b, stride, dtype, leaky=leaky, residual=r, splitk=sk, info=info, **kw)
+            n_split += info.get("splits", 1) > 1
+            assert got.shape == want.shape, (it, dtype, ks, stride, H, B, C, O, mode, sk)
+            assert np.all(np.abs(got - want) <= tol), (it, dtype, ks, stride, H, B, C, O, mode, sk, float(np.abs(got - want).max()))
+        n_cases += 1
+    assert n_cases == 36 and n_split >= 4
