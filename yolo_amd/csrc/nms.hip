@@ -56,12 +56,14 @@ __device__ __forceinline__ NBox norm_box(const f32x4 b) {
     return n;
 }
 __device__ __forceinline__ bool iou_gt_norm(const NBox &i, const NBox &j, float thr) {
-    if (i.area <= 0.0f || j.area <= 0.0f) return false;
+    // branch-free (the early return cost a divergent branch per slot and round); same arithmetic for valid pairs,
+    // and an invalid pair's quotient (possibly inf / NaN) is masked
+    const bool valid = (i.area > 0.0f) & (j.area > 0.0f);
     const float iymin = vmax_raw(i.ymin, j.ymin), ixmin = vmax_raw(i.xmin, j.xmin);      // boxes are finite: raw min/max
     const float iymax = vmin_raw(i.ymax, j.ymax), ixmax = vmin_raw(i.xmax, j.xmax);
     const float inter = fmaxf(iymax - iymin, 0.0f) * fmaxf(ixmax - ixmin, 0.0f);
     const float iou = inter / (i.area + j.area - inter);
-    return iou > thr;
+    return valid & (iou > thr);
 }
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
@@ -209,10 +211,12 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
             } else {
                 win = *(const f32x4 *)(rec + (long)win_idx * 8);
             }
-            if (tid == 0) { kidx[kept] = win_idx; s_kept[kept] = win_idx; }
+            if (tid == 0) s_kept[kept] = win_idx;                // written out once below (see nms_block_kernel)
             ++kept;
         }
         if (tid == 0) kept_count[pair] = kept;
+        __syncthreads();                                         // s_kept complete
+        if (tid < kept) kidx[tid] = s_kept[tid];
 
         // ---- optional: tf nms_index = position in the order-preserving class-masked array ----
         if (kept_rank != nullptr) {
@@ -416,7 +420,9 @@ __global__ __launch_bounds__(kThreads) void nms_block_kernel(const float *record
             for (int w = 1; w < 4; ++w) { const unsigned long long v = s_key[kept & 1][w]; if (v > best) { best = v; ww = w; } }
             if (best == 0ull) break;                             // nothing alive (block-uniform)
             const NBox win = norm_box(s_box[kept & 1][ww]);
-            if (tid == 0) { const int wi = (int)(~(unsigned)best); kidx[kept] = wi; s_kept[kept] = wi; }
+            // (kept indices go to LDS and are written out once at the end: a global store here would be drained by the
+            // fence in every round's __syncthreads -- ~2 us of store latency on the critical path of each round)
+            if (tid == 0) s_kept[kept] = (int)(~(unsigned)best);
             ++kept;
 #pragma unroll
             for (int k = 0; k < kBSlots; ++k) {
@@ -429,6 +435,8 @@ __global__ __launch_bounds__(kThreads) void nms_block_kernel(const float *record
             }
         }
         if (tid == 0) kept_count[pair] = kept;
+        __syncthreads();                                         // s_kept complete
+        if (tid < kept) kidx[tid] = s_kept[tid];
         if (kept_rank != nullptr) {
             s_rank[tid] = 0;
             __syncthreads();
