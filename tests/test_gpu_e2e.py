@@ -419,3 +419,41 @@ def test_splitk_small_batch_mode(dtype, size):
         else:
             assert np.abs(s_ - r).max() / np.abs(r).max() <= 2e-2
             assert np.abs(s_ - u_).max() / np.abs(r).max() <= 1e-2
+
+
+def test_config1_against_committed_fixture():
+    """BASELINE config 1 (YOLOv3-tiny 416, batch 1, fp32) against the committed fixture tests/golden/tiny416_b1.npz
+    (oracle output; generating script beside it): heads within 1e-3, and the detections -- class, box within half a
+    pixel, score within 2e-3 -- for at least 98 % of the fixture's boxes (a 1e-3 head difference may flip a
+    near-threshold box or an IoU sitting on 0.3)."""
+    import importlib.util
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gold, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = np.load(os.path.join(gold, "tiny416_b1.npz"))
+    layers, oi = od.parse_layers(config.yolov3_tiny_cfg_path, 80)
+    params = dw.random_params(layers, seed=1)
+    x = np.random.default_rng(0).random((1, 416, 416, 3), dtype=np.float32)
+    net = build_model.Network(config.yolov3_tiny_cfg_path, 80, dtype="fp32")
+    net.set_params(params)
+    heads = net(torch.from_numpy(x))
+    for k, h in enumerate(heads):
+        hn = h.cpu().numpy()
+        assert list(hn.shape) == list(want["head%d_shape" % k])
+        assert np.abs(hn.reshape(-1)[::mg.STRIDE] - want["head%d_sub" % k]).max() <= 1e-3
+        assert abs(hn.astype(np.float64).sum() - want["head%d_sum" % k][0]) <= 1e-4 * want["head%d_sum" % k][1]
+    anchors = inference.read_anchors(config.tiny_anchors_path)
+    old = config.score_threshold
+    config.score_threshold = mg.SCORE_THR
+    try:
+        boxes, scores, classes = (t.cpu().numpy() for t in inference.predict(heads, anchors, 80, (416, 416), (375, 500)))
+    finally:
+        config.score_threshold = old
+    wb, ws_, wc = want["boxes"], want["scores"], want["classes"]
+    assert abs(len(classes) - len(wc)) <= 3
+    hit = 0
+    for i in range(len(wc)):
+        m = (classes == wc[i]) & (np.abs(boxes - wb[i]).max(axis=1) <= 0.5) & (np.abs(scores - ws_[i]) <= 2e-3)
+        hit += bool(m.any())
+    assert hit >= 0.98 * len(wc)

@@ -224,3 +224,22 @@ def test_select_contract():
     np.testing.assert_array_equal(boxes[pool], b)
     lines = odec.label_lines(b, s, c, (100, 100))
     assert len(lines) == len(c) and lines[0].split(",")[4] == str(int(c[-1]))    # reversed order (inference.py:291)
+
+
+def test_oracle_reproduces_committed_config1_fixture():
+    """tests/golden/tiny416_b1.npz (made by tests/golden/make_golden.py from this oracle): BASELINE config 1.
+    Guards the oracle against drift: head tensors (strided subsample + sums) and the final detections."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    got = mg.compute()[-1]
+    want = np.load(os.path.join(GOLD, "tiny416_b1.npz"))
+    for k in (0, 1):
+        np.testing.assert_array_equal(got["head%d_shape" % k], want["head%d_shape" % k])
+        np.testing.assert_allclose(got["head%d_sub" % k], want["head%d_sub" % k], rtol=0, atol=2e-5)     # BLAS summation order
+        np.testing.assert_allclose(got["head%d_sum" % k], want["head%d_sum" % k], rtol=1e-6)
+    assert len(got["classes"]) == len(want["classes"]) > 100
+    np.testing.assert_array_equal(got["classes"], want["classes"])
+    np.testing.assert_allclose(got["boxes"], want["boxes"], rtol=0, atol=1e-2)
+    np.testing.assert_allclose(got["scores"], want["scores"], rtol=0, atol=1e-5)
