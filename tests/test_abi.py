@@ -51,3 +51,18 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libyolo3hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_committed_traffic_file_names_the_bench_kernels():
+    """bench.py takes roofline.traffic from profiles/traffic.json by kernel-name prefix: the file must exist, point at a
+    committed summary, and carry the kernels of the default plan (so that `traffic` is never silently null)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tj = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    src = tj["source"].split(" ")[0]
+    assert os.path.exists(os.path.join(root, src)), src
+    names = tj["hbm_bytes_per_launch"]
+    for prefix in ("conv_igemm_kernel<true, 256, 256, 2, 4", "conv_igemm_kernel<true, 192, 256, 2, 4", "conv_stem_kernel",
+                   "decode_lane_kernel"):
+        hits = [v for k, v in names.items() if k.startswith(prefix)]
+        assert len(hits) == 1 and hits[0] > 0, prefix
