@@ -39,7 +39,9 @@ enum {
     Y3_CONV_UPS2X = 4,     /* store each output pixel 2x2 (nearest upsample, :231-239)       */
     Y3_CONV_OUT_F32 = 8,   /* store fp32 regardless of compute dtype (head tensors)          */
     Y3_CONV_IN_F32 = 16,   /* input is fp32 regardless of compute dtype (first layer image)  */
-    Y3_CONV_REVERSE = 32   /* scheduling hint, same result: output tiles are walked last to first */
+    Y3_CONV_REVERSE = 32,  /* scheduling hint, same result: output tiles are walked last to first */
+    Y3_CONV_POOL2 = 64     /* first layer only (3x3 s1, 3 fp32 channels, even size): `out` receives the 2x2 stride-2 max pool
+                              of the activated output (tf.nn.max_pool, build_model.py:203-212), [B, out_h/2, out_w/2, out_ld]  */
 };
 
 /* One fused convolution: conv (+folded BN) + bias [+ leaky] [+ residual] [2x upsampled store].

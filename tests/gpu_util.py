@@ -23,7 +23,7 @@ def to_dev(x, dtype):
 
 
 def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=False, out_f32=False, in_f32=False,
-             in_pad=(0, 0), out_pad=(0, 0), splitk=False, info=None):
+             in_pad=(0, 0), out_pad=(0, 0), splitk=False, info=None, pool=False):
     """x NHWC fp32 numpy; kernel HWIO; returns the NHWC fp32 numpy output.  in_pad/out_pad =
     (channels before, channels after) embed the tensor in a wider buffer (route slices)."""
     lib = _lib.load()
@@ -41,6 +41,8 @@ def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=Fals
     out_ld = out_pad[0] + o8 + out_pad[1]
     odt = torch.float32 if (out_f32 or dtype == "fp32") else torch.bfloat16
     Hs, Ws = (2 * Ho, 2 * Wo) if ups else (Ho, Wo)
+    if pool:            # Y3_CONV_POOL2: the launch writes the 2x2 stride-2 max pool of its output
+        Hs, Ws = Ho // 2, Wo // 2
     out = torch.full((B, Hs, Ws, out_ld), -9.0, dtype=odt, device="cuda")
     res_t, res_ld = None, 0
     if residual is not None:
@@ -54,7 +56,8 @@ def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=Fals
     d.out_h, d.out_w, d.out_c, d.out_ld, d.res_ld = Ho, Wo, O, out_ld, res_ld
     d.ksize, d.stride, d.k_pad, d.n_pad = ks, stride, k_pad, n_pad
     d.flags = ((_lib.CONV_LEAKY if leaky else 0) | (_lib.CONV_RESIDUAL if residual is not None else 0)
-               | (_lib.CONV_UPS2X if ups else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_IN_F32 if in_f32 else 0))
+               | (_lib.CONV_UPS2X if ups else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_IN_F32 if in_f32 else 0)
+               | (_lib.CONV_POOL2 if pool else 0))
     es_in = xin.element_size()
     es_out = out.element_size()
     if splitk:          # y3_conv2d_splitk with the workspace its plan asks for (splits == 1: same as y3_conv2d_fused)

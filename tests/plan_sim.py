@@ -69,7 +69,10 @@ class Sim(object):
                 if op["res"] is not None:
                     y = y + self.read(op["res"], B * oh * ow)
                 y = y.astype(np.float32)
-                if op["ups"]:
+                if op.get("pool"):                      # 2x2 stride-2 max pool fused into the first convolution
+                    y = y.reshape(B, oh // 2, 2, ow // 2, 2, oc).max(axis=(2, 4)).reshape(-1, oc)
+                    self.write(op["y"], np.arange(B * (oh // 2) * (ow // 2)), y)
+                elif op["ups"]:
                     b, r = np.divmod(np.arange(B * oh * ow), oh * ow)
                     ho, wo = np.divmod(r, ow)
                     for dy in (0, 1):

@@ -112,6 +112,27 @@ def test_conv_first_layer_direct(dtype, cout):
     assert np.all(np.abs(got - want) <= tol)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 16, 20, 16), (1, 34, 6, 24), (3, 8, 8, 32)], ids=str)
+def test_conv_first_layer_with_pool(case, dtype):
+    """Y3_CONV_POOL2 (YOLOv3-tiny layers 0-1 in one launch) == the same convolution followed by the 2x2 stride-2
+    max pool, bit for bit (and both against the oracle); bad shapes are refused."""
+    from oracle import darknet as od
+    B, H, W, O = case
+    rng = np.random.default_rng(H * 100 + O)
+    x = rng.random((B, H, W, 3), dtype=np.float32)
+    k = (rng.standard_normal((3, 3, 3, O)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32)
+    full = gpu_util.run_conv(x, k, b, 1, dtype, leaky=True, in_f32=True)
+    fused = gpu_util.run_conv(x, k, b, 1, dtype, leaky=True, in_f32=True, pool=True)
+    np.testing.assert_array_equal(fused, od.max_pool_same(full, 2, 2))
+    want = od.max_pool_same(_ref(x, k, b, 1, True), 2, 2)
+    tol = 1e-4 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(want))
+    assert np.all(np.abs(fused - want) <= tol)
+    with pytest.raises(ValueError):          # odd output size
+        gpu_util.run_conv(x[:, :H - 1], k, b, 1, dtype, leaky=True, in_f32=True, pool=True)
+
+
 @pytest.mark.parametrize("has_c", [True, False])
 @pytest.mark.parametrize("shape", [(2, 64, 64), (1, 48, 80), (1, 37, 45), (3, 16, 32)], ids=str)
 def test_conv_stem_fused(shape, has_c):

@@ -28,7 +28,9 @@ def _check(cfg, size, batch, fuse, pad_input=False):
 def test_tiny_plan_matches_oracle(fuse):
     plan = _check(config.yolov3_tiny_cfg_path, 416, 1, fuse)
     kinds = [op["kind"] for op in plan.ops]
-    assert kinds.count("conv") == 13 and kinds.count("maxpool") == 6
+    # fused: the first max pool (2x2 stride 2) is taken by the first convolution's kernel
+    assert kinds.count("conv") == 13 and kinds.count("maxpool") == (5 if fuse else 6)
+    assert bool(plan.ops[0].get("pool")) == fuse and sum(1 for op in plan.ops if op.get("pool")) == (1 if fuse else 0)
     assert kinds.count("upsample") == (0 if fuse else 1) and "copy" not in kinds
 
 

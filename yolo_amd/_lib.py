@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOLO3HIP_LIB") or os.path.join(_HERE, "libyolo3hip.so")     # override: A/B builds
 
 Y3_F32, Y3_BF16 = 0, 1
-CONV_LEAKY, CONV_RESIDUAL, CONV_UPS2X, CONV_OUT_F32, CONV_IN_F32, CONV_REVERSE = 1, 2, 4, 8, 16, 32
+CONV_LEAKY, CONV_RESIDUAL, CONV_UPS2X, CONV_OUT_F32, CONV_IN_F32, CONV_REVERSE, CONV_POOL2 = 1, 2, 4, 8, 16, 32, 64
 
 c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 

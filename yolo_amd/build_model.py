@@ -136,6 +136,7 @@ class _CompiledPlan(object):
             if op["out_f32"]: flags |= _lib.CONV_OUT_F32
             if op["in_f32"]: flags |= _lib.CONV_IN_F32
             if op.get("reverse"): flags |= _lib.CONV_REVERSE
+            if op.get("pool"): flags |= _lib.CONV_POOL2
             d.flags = flags
             dref = ctypes.byref(d)
             name = ctypes.create_string_buffer(96)

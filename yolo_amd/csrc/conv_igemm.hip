@@ -803,6 +803,86 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirectArgs p) {
     }
 }
 
+// First layer + the 2x2 stride-2 max pool that follows it (YOLOv3-tiny: conv 3->16 @416, maxpool), Y3_CONV_POOL2:
+// one thread per POOLED pixel and 16 output channels.  The 4x4xCIN input patch is loaded once; each of the four
+// convolution outputs under the pool window is the same sequential fmaf chain over k as in conv_direct_kernel
+// (+ bias, leaky), so max-then-round equals the unfused round-then-max bit for bit (rounding is monotonic).
+// The full-resolution activation (the largest tensor of the network) never reaches HBM.
+template <bool OUT_BF16, int CIN>
+__global__ __launch_bounds__(256) void conv_direct_pool_kernel(const DirectArgs p) {
+    constexpr int CT = 16;
+    const int Wp = p.Wo >> 1, HpWp = (p.Ho >> 1) * Wp;
+    const int gm = blockIdx.x * 256 + threadIdx.x;           // pooled pixel
+    const int nb = blockIdx.y * CT;
+    if (gm >= p.M) return;
+    const int b = gm / HpWp;
+    const int r = gm - b * HpWp;
+    const int hp = r / Wp;
+    const int wp = r - hp * Wp;
+    const int hi0 = 2 * hp - 1, wi0 = 2 * wp - 1;
+    float patch[4][4][CIN];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int hi = hi0 + dy, wi = wi0 + dx;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const long pix = ok ? ((long)b * p.H + hi) * p.W + wi : 0;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float x = ((const float *)p.in)[pix * p.in_ld + c];
+                patch[dy][dx][c] = ok ? x : 0.0f;
+            }
+        }
+    float acc[4][CT];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[o][j] = 0.0f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float *wr = p.w + (long)((kh * 3 + kw) * CIN + c) * p.n_pad + nb;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float x = patch[(o >> 1) + kh][(o & 1) + kw][c];
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) acc[o][j] = fmaf(x, wr[j], acc[o][j]);
+                }
+            }
+    const bool leaky = p.flags & Y3_CONV_LEAKY;
+    float best[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const float bj = p.bias[nb + j];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = acc[o][j] + bj;
+            if (leaky) v = leaky01(v);
+            best[j] = o == 0 ? v : fmaxf(best[j], v);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CT; j += 8) {
+        if (nb + j >= p.Cout8) break;
+        if constexpr (OUT_BF16) {
+            u32x4 o;
+            o[0] = pack_bf16x2(best[j], best[j + 1]);
+            o[1] = pack_bf16x2(best[j + 2], best[j + 3]);
+            o[2] = pack_bf16x2(best[j + 4], best[j + 5]);
+            o[3] = pack_bf16x2(best[j + 6], best[j + 7]);
+            *(u32x4 *)(p.out + ((long)gm * p.out_ld + nb + j) * 2) = o;
+        } else {
+            float *op = (float *)p.out + (long)gm * p.out_ld + nb + j;
+            *(f32x4 *)op = f32x4{best[j], best[j + 1], best[j + 2], best[j + 3]};
+            *(f32x4 *)(op + 4) = f32x4{best[j + 4], best[j + 5], best[j + 6], best[j + 7]};
+        }
+    }
+}
+
 template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS, bool IL>
 int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
     constexpr int stage_bytes = 2 * (BM + BN) * 128;
@@ -986,6 +1066,20 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
     if (family == 1) {
         Y3_REQUIRE(!(d->flags & (Y3_CONV_RESIDUAL | Y3_CONV_UPS2X)), Y3_E_INVALID, "conv(direct): residual/upsample unsupported");
         DirectArgs a;
+        if (d->flags & Y3_CONV_POOL2) {        // conv 3x3 s1 (Cin = 3, fp32 input) + maxpool 2x2 s2 in one launch; `out` is the pooled tensor
+            const bool in_f32 = !bf16 || (d->flags & Y3_CONV_IN_F32);
+            Y3_REQUIRE(d->ksize == 3 && d->stride == 1 && d->in_c == 3 && in_f32 && d->out_h % 2 == 0 && d->out_w % 2 == 0, Y3_E_INVALID,
+                       "conv(pool2): needs 3x3 stride 1, 3 fp32 input channels and even output size (got k%d s%d c%d %dx%d)",
+                       d->ksize, d->stride, d->in_c, d->out_h, d->out_w);
+            a.in = (const char *)in; a.w = (const float *)w; a.bias = bias; a.out = (char *)out;
+            a.H = d->in_h; a.W = d->in_w; a.Cin = d->in_c; a.in_ld = d->in_ld;
+            a.Ho = d->out_h; a.Wo = d->out_w; a.HoWo = d->out_h * d->out_w; a.Cout8 = cout8; a.out_ld = d->out_ld;
+            a.ks = 3; a.stride = 1; a.pad = 1; a.n_pad = d->n_pad; a.M = (int)(M / 4); a.flags = d->flags;
+            dim3 grid((unsigned)((a.M + 255) / 256), (unsigned)((cout8 + 15) / 16));
+            if (out_f32) hipLaunchKernelGGL((conv_direct_pool_kernel<false, 3>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_direct_pool_kernel<true, 3>), grid, dim3(256), 0, stream, a);
+            return y3_check_launch("conv_direct_pool");
+        }
         a.in = (const char *)in; a.w = (const float *)w; a.bias = bias; a.out = (char *)out;
         a.H = d->in_h; a.W = d->in_w; a.Cin = d->in_c; a.in_ld = d->in_ld;
         a.Ho = d->out_h; a.Wo = d->out_w; a.HoWo = d->out_h * d->out_w; a.Cout8 = cout8; a.out_ld = d->out_ld;
@@ -1219,7 +1313,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     if (family < 0) return family;
     const char *t = d->dtype == Y3_BF16 ? "true" : "false";
     if (family == 1) {
-        snprintf(buf, (size_t)len, "conv_direct_kernel");
+        snprintf(buf, (size_t)len, (d->flags & Y3_CONV_POOL2) ? "conv_direct_pool_kernel" : "conv_direct_kernel");
         return Y3_OK;
     }
     const long M = (long)d->batch * d->out_h * d->out_w;

@@ -234,6 +234,22 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
             fused_into[i] = p
             absorbed[p] = i
 
+        # the first convolution (3 input channels: the direct kernel) absorbs a 2x2 stride-2 max pool that follows it
+        # (YOLOv3-tiny layers 0-1): the full-resolution activation, the largest tensor of the network, is never stored
+        for i, L in enumerate(layers):
+            if L["type"] != "maxpool" or (L["size"], L["stride"]) != (2, 2) or pad_input:
+                continue
+            p = inputs[i][0]
+            if p < 0 or layers[p]["type"] != "conv" or uses[p] != 1 or p in head_of or p in absorbed:
+                continue
+            if stem_layers is not None and p in stem_layers:
+                continue
+            P = layers[p]
+            if inputs[p] != [-1] or in_c != 3 or (P["size"], P["stride"]) != (3, 1) or shapes[p][0] % 2 or shapes[p][1] % 2:
+                continue
+            fused_into[i] = p
+            absorbed[p] = i
+
     # ---- storage: aliases, concat slices, own buffers ---------------------------------------
     bufs = []            # dict(elems, es, kind)
     tens = [None] * n    # dict(buf, off, ld, c)  (off/ld in elements)
@@ -327,18 +343,20 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
                 xin, in_f32, ic = padded_in, False, epc
             op = dict(kind="conv", layer=i, x=xin, in_hw=(ih, iw), in_c=ic, out_hw=(oh, ow), out_c=oc,
                       ksize=L["size"], stride=L["stride"], leaky=L["activation"] == "leaky",
-                      in_f32=in_f32, out_f32=(i in head_of), res=None, ups=False)
+                      in_f32=in_f32, out_f32=(i in head_of), res=None, ups=False, pool=False)
             tgt = i
             if i in absorbed:
                 tgt = absorbed[i]
                 if layers[tgt]["type"] == "shortcut":
                     op["res"] = tens[layers[tgt]["src"]]
+                elif layers[tgt]["type"] == "maxpool":
+                    op["pool"] = True
                 else:
                     op["ups"] = True
             op["y"] = tens[tgt]
             op["writes_layer"] = tgt
             ops.append(op)
-        elif t == "maxpool":
+        elif t == "maxpool" and i not in fused_into:
             src = inputs[i][0]
             ops.append(dict(kind="maxpool", layer=i, x=tin(src), y=tens[i], in_hw=shapes[src][:2], c=shapes[i][2],
                             size=L["size"], stride=L["stride"]))
@@ -433,7 +451,7 @@ def op_bytes(op, batch, es):
     if op["kind"] == "conv":
         oh, ow = op["out_hw"]; ih, iw = op["in_hw"]
         byt = batch * ih * iw * op["in_c"] * (4 if op["in_f32"] else es)
-        byt += batch * oh * ow * op["out_c"] * (4 if op["out_f32"] else es) * (4 if op["ups"] else 1)
+        byt += batch * oh * ow * op["out_c"] * (4 if op["out_f32"] else es) * (4 if op["ups"] else 1) // (4 if op.get("pool") else 1)
         byt += op["out_c"] * op["ksize"] ** 2 * op["in_c"] * es
         if op["res"] is not None:
             byt += batch * oh * ow * op["out_c"] * es
