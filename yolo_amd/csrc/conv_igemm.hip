@@ -809,11 +809,17 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirectArgs p) {
 // (+ bias, leaky), so max-then-round equals the unfused round-then-max bit for bit (rounding is monotonic).
 // The full-resolution activation (the largest tensor of the network) never reaches HBM.
 template <bool OUT_BF16, int CIN>
-__global__ __launch_bounds__(256) void conv_direct_pool_kernel(const DirectArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // 258 registers would halve the occupancy
+void conv_direct_pool_kernel(const DirectArgs p) {
     constexpr int CT = 16;
     const int Wp = p.Wo >> 1, HpWp = (p.Ho >> 1) * Wp;
-    const int gm = blockIdx.x * 256 + threadIdx.x;           // pooled pixel
     const int nb = blockIdx.y * CT;
+    // this block's 27 x CT weights in LDS: as wave-uniform scalar loads the unrolled loop below keeps all 432 live
+    // and the compiler spills them lane by lane (1 800 v_readlane per thread); broadcast ds_reads cost nothing like that
+    __shared__ __attribute__((aligned(16))) float wsm[9 * CIN * CT];
+    for (int i = threadIdx.x; i < 9 * CIN * CT; i += 256) wsm[i] = p.w[(long)(i / CT) * p.n_pad + nb + (i % CT)];
+    __syncthreads();
+    const int gm = blockIdx.x * 256 + threadIdx.x;           // pooled pixel
     if (gm >= p.M) return;
     const int b = gm / HpWp;
     const int r = gm - b * HpWp;
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(256) void conv_direct_pool_kernel(const DirectArgs 
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
-                const float *wr = p.w + (long)((kh * 3 + kw) * CIN + c) * p.n_pad + nb;
+                const float *wr = wsm + ((kh * 3 + kw) * CIN + c) * CT;
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const float x = patch[(o >> 1) + kh][(o & 1) + kw][c];
