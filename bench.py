@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=0, help="sub-batch the plan runs at a time (0 = whole batch)")
     ap.add_argument("--score-threshold", type=float, default=config.score_threshold)
+    ap.add_argument("--max-boxes", type=int, default=config.max_boxes, help="per-class NMS cap (experiments; the reference's 51 is the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24, help="timed images of the CPU baseline (plus 1 warm-up)")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -109,6 +110,7 @@ def main():
     cfg = config.yolov3_tiny_cfg_path if args.model == "yolov3-tiny" else config.yolov3_cfg_path
     anchors = inference.read_anchors(config.tiny_anchors_path if args.model == "yolov3-tiny" else config.anchors_path)
     config.score_threshold = args.score_threshold
+    config.max_boxes = args.max_boxes
     B, S = args.batch, args.size
 
     nodes = build_model.yolo(None, False, cfg, config.num_classes, dtype=args.dtype, device=dev, splitk=args.splitk)
