@@ -106,6 +106,10 @@ def main():
     assert world == args.gpus or world == 1, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one process per GPU: this rank's kernels, arena and events all live on its own device (checked before any launch)
+    assert torch.cuda.current_device() == local_rank, "rank %d bound to cuda:%d, expected cuda:%d" % (
+        rank, torch.cuda.current_device(), local_rank)
+    assert rehearsal or world <= torch.cuda.device_count(), "%d ranks but %d visible GPUs" % (world, torch.cuda.device_count())
 
     cfg = config.yolov3_tiny_cfg_path if args.model == "yolov3-tiny" else config.yolov3_cfg_path
     anchors = inference.read_anchors(config.tiny_anchors_path if args.model == "yolov3-tiny" else config.anchors_path)
@@ -181,6 +185,7 @@ def main():
     elapsed = float(t.item())
 
     counts = sharding.gather_counts(det.count)                    # the one collective, off the timed path
+    assert counts.numel() == world * B, "gathered %d counts, expected %d ranks x %d images" % (counts.numel(), world, B)
     total_images = world * B * args.steps
     value = total_images / elapsed
 
@@ -193,11 +198,16 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s %dx%d, batch %d per GPU, %s, seeded random-init Darknet weights, backbone + "
-                                   "decode + per-class NMS (score>=%.3g, iou>0.3, max 51/class)"
-                                   % (args.model, S, S, B, args.dtype, args.score_threshold),
+                                   "decode + per-class NMS (score>=%.3g, iou>%.3g, max %d/class)"
+                                   % (args.model, S, S, B, args.dtype, config.score_threshold, config.nms_threshold,
+                                      config.max_boxes),
                        "global_batch": world * B, "parallelism": "dp%d (image-sharded, no data-path collective)" % world,
                        "chunk": chunk or B, "launch": "hip graph replay" if args.graph else "eager", "conv_gflop_per_image": round(gflop_img, 3),
                        "mean_detections_per_image": round(float(counts.float().mean().item()), 2)},
+            # what the collective layer saw (the driver's scaling run can check that RCCL really spanned N ranks)
+            "distributed": {"backend": dist.get_backend() if world > 1 else "none",
+                            "world": dist.get_world_size() if world > 1 else 1,
+                            "ranks_reporting": counts.numel() // B, "device_of_rank0": torch.cuda.current_device()},
             "conv_mfma_util_pct_end_to_end": round(100.0 * gflop_img * value / world / 1e3 /
                                                    (BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS), 2),
         }

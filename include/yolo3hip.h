@@ -6,8 +6,12 @@
  * site(s) cited beside it.  Conventions:
  *   - plain pointers and ints only; every pointer is a DEVICE pointer unless it
  *     is a descriptor struct (host) or says "host";
- *   - the library never allocates or frees device memory and keeps no state
- *     besides a thread-local error string; the caller owns every buffer;
+ *   - the library never allocates or frees device memory and keeps no mutable state
+ *     besides a thread-local error string (plus read-only per-device facts it caches: the
+ *     compute-unit count, which kernels already have their LDS attribute set); there is no
+ *     setter, knob or mode switch in it -- the tile/variant overrides used by A/B runs and by
+ *     the tile-equality tests exist only in the -DY3_EXPERIMENTS flavour of the library
+ *     (libyolo3hip_exp.so, include/yolo3hip_experimental.h); the caller owns every buffer;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
  *     re-entrant across streams/devices, and does not synchronise;
  *   - return 0 on success, <0 on error (Y3_E_*); y3_last_error() describes it.
@@ -22,7 +26,7 @@
 extern "C" {
 #endif
 
-#define Y3_VERSION 100
+#define Y3_VERSION 101
 
 enum { Y3_F32 = 0, Y3_BF16 = 1 };
 
@@ -109,13 +113,6 @@ int y3_conv_stem(const y3_stem_desc *desc, const float *image, const float *w0, 
 /* Name (prefix) of the kernel a descriptor will run on, as rocprofv3 reports it. Host-only. */
 int y3_conv_kernel_name(const y3_conv_desc *desc, char *buf, int len);
 
-/* Tuning knob for experiments: force the implicit-GEMM tile (0 = heuristic, 128, 256). Process-global. */
-int y3_set_conv_tile(int tile);
-/* Tuning knob: start offset of the de-phased persistent workgroups in percent of a tile period (default 50, 0 = off). */
-int y3_set_conv_phase(int percent);
-/* Tuning knob: CUs one convolution launch may occupy (default 256; two streams with 128 each overlap two layers). */
-int y3_set_conv_cus(int cus);
-
 /* tf.nn.max_pool(padding='SAME'), build_model.py:207-210.  c % (16/elsize) == 0. */
 int y3_maxpool2d(int dtype, const void *in, void *out, int batch, int in_h, int in_w, int c,
                  int in_ld, int out_ld, int size, int stride, void *stream);
@@ -157,9 +154,6 @@ typedef struct y3_decode_desc {
 int y3_decode(const y3_decode_desc *desc, const float *head0, const float *head1, const float *head2,
               const float *letterbox, float *records, int32_t *cand_idx, int32_t *cand_count,
               int32_t *class_count, void *stream);
-
-/* Test knob: 1 = always the 16-lanes-per-box decode kernel, 0 = automatic (lane-per-box when shapes allow). */
-int y3_decode_variant(int v);
 
 /* Dense forms kept for API parity with the reference's helper functions. */
 /* get_head (utils/utils.py:43-96) for one scale: xy,wh [cells*A*2], conf [cells*A], cls [cells*A*C]. */

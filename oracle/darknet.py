@@ -237,6 +237,72 @@ def forward(layers, out_index, params, x, round_fn=None, collect=False):
     return (heads, all_layers) if collect else heads
 
 
+def bf16_round(a):
+    """fp32 -> nearest bfloat16 (ties to even) -> fp32, on the bit pattern (finite inputs)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)
+    return r.view(np.float32)
+
+
+def forward_bf16_model(layers, out_index, params, x, collect=False, first_conv_fp32=False):
+    """The same graph with bf16 STORAGE modelled: what the reference's fp32 graph becomes when weights and
+    activations are kept in bfloat16 and every sum runs in fp32 (the build's bf16 mode, BASELINE north_star
+    "bf16 MFMA").  Batch norm is folded into the kernel (float64, then fp32, then bf16); the network input and
+    every layer output are rounded to bf16 once -- a shortcut's sum (build_model.py:223-225) is rounded once, after
+    the fp32 add of the un-rounded convolution output, and the head tensors stay fp32.  first_conv_fp32: the first
+    convolution reads the fp32 image with fp32 weights (how the build runs a 3-channel first layer outside
+    Darknet-53's fused stem, e.g. YOLOv3-tiny's).  Separates the two error
+    sources of a bf16 run: bf16 storage itself (this model vs `forward`) and the kernels' arithmetic (GPU vs
+    this model, where only fp32 summation order and the bf16 roundings it flips remain)."""
+    x = np.asarray(x, dtype=np.float32)
+    x = x if first_conv_fp32 else bf16_round(x)
+    all_layers, pre = [], {}
+    prev = x
+    heads = set(out_index)
+    first = next(i for i, L in enumerate(layers) if L["type"] == "conv")
+    for li, L in enumerate(layers):
+        t = L["type"]
+        if t == "conv":
+            p = params[li]
+            k = p["kernel"].astype(np.float64)
+            if L["bn"]:
+                s = p["gamma"].astype(np.float64) / np.sqrt(p["var"].astype(np.float64) + 1e-5)
+                k, b = k * s, p["beta"].astype(np.float64) - p["mean"].astype(np.float64) * s
+            else:
+                b = p["bias"].astype(np.float64)
+            k, b = k.astype(np.float32), b.astype(np.float32)
+            if not (first_conv_fp32 and li == first):
+                k = bf16_round(k)
+            if L["stride"] > 1:
+                prev = np.pad(prev, ((0, 0), (1, 0), (1, 0), (0, 0)))
+            y = conv2d(prev, k, L["stride"], L["same"]) + b
+            if L["activation"] == "leaky":
+                y = leaky_relu(y)
+            y = y.astype(np.float32)
+            pre[li] = y
+            prev = y if li in heads else bf16_round(y)
+            all_layers.append(prev)
+        elif t == "route":
+            srcs = [all_layers[i] for i in L["ids"]]
+            prev = srcs[0] if len(srcs) == 1 else np.concatenate(srcs, axis=-1)
+            all_layers.append(prev)
+        elif t == "maxpool":
+            prev = max_pool_same(prev, L["size"], L["stride"])
+            all_layers.append(prev)
+        elif t == "shortcut":
+            a = pre.get(li - 1, prev)                       # the producing convolution's fp32 value
+            prev = bf16_round((all_layers[L["src"]] + a).astype(np.float32))
+            all_layers.append(prev)
+        elif t == "upsample":
+            prev = upsample2x_nearest(prev)
+            all_layers.append(prev)
+        elif t == "yolo":
+            all_layers.append(None)
+            prev = None
+    heads_out = [all_layers[i] for i in out_index]
+    return (heads_out, all_layers) if collect else heads_out
+
+
 def conv_gflops(layers, height, width):
     """2*MAC count of the convs, for the topology check against Darknet's BFLOPs."""
     shapes = []

@@ -11,8 +11,8 @@ from yolo_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "yolo3hip.h")).read()
+def _declared(header="yolo3hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(y3_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,8 +26,26 @@ def test_header_symbols_exported_and_bound():
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
 
 
+def test_product_library_has_no_knobs():
+    """The tile / phase / CU / decode-variant setters (and the timing paths behind them) exist only in the
+    -DY3_EXPERIMENTS flavour: libyolo3hip.so exports none of them, libyolo3hip_exp.so exports the product ABI plus
+    exactly what include/yolo3hip_experimental.h declares."""
+    knobs = _declared("yolo3hip_experimental.h")
+    assert knobs == sorted(_lib.EXPERIMENTAL_SIGNATURES) and "y3_set_conv_tile" in knobs
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    exp = ctypes.CDLL(_lib.EXP_LIB_PATH)
+    for n in knobs:
+        assert not hasattr(lib, n), "libyolo3hip.so exports the experiment knob %s" % n
+        assert hasattr(exp, n)
+    for n in _declared():
+        assert hasattr(exp, n)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "y3_conv2d_fused" in syms and "y3_set_conv" not in syms and "y3_decode_variant" not in syms
+
+
 def test_version_and_layout(lib):
-    assert lib.y3_version() == 100
+    assert lib.y3_version() == 101
     assert _lib.conv_weight_layout(_lib.Y3_BF16, 3, 32, 3, in_f32=True) == (1, 27, 32)
     assert _lib.conv_weight_layout(_lib.Y3_BF16, 32, 64, 3) == (0, 320, 64)
     assert _lib.conv_weight_layout(_lib.Y3_BF16, 1024, 255, 1) == (0, 1024, 256)

@@ -227,7 +227,7 @@ def test_conv_tile256_equals_tile128(case, dtype):
     want = _ref(x, k, b, stride, leaky, residual=r)
     tol = 1e-3 if dtype == "fp32" else 1e-2 * np.maximum(1.0, np.abs(want))
     outs = {}
-    try:
+    with _lib.experimental() as lib:          # libyolo3hip_exp.so: the product library has no tile override
         for res in (r, None):
             for tile in reg_family + lds_family:
                 _lib.check(lib.y3_set_conv_tile(tile))
@@ -241,8 +241,9 @@ def test_conv_tile256_equals_tile128(case, dtype):
                     np.testing.assert_array_equal(outs[fam[0]], outs[tile])
             if dtype == "fp32":      # one epilogue only
                 np.testing.assert_array_equal(outs[reg_family[0]], outs[lds_family[0]])
-    finally:
-        lib.y3_set_conv_tile(0)
+    # ... and the product library's own choice for this shape gives the same bits as its family
+    dflt = gpu_util.run_conv(x, k, b, stride, dtype, leaky=leaky, residual=None)
+    np.testing.assert_array_equal(dflt, outs[reg_family[0]] if dtype == "bf16" else outs[lds_family[0]])
 
 
 def test_conv_cout64_tile_variants_agree():
@@ -258,15 +259,14 @@ def test_conv_cout64_tile_variants_agree():
     r = gpu_util.bf16_round(rng.standard_normal((B, H, H, O)).astype(np.float32))
     want = _ref(x, k, b, 1, True, residual=r)
     outs = {}
-    try:
+    with _lib.experimental() as lib:
         for tile in (0, 64, 261):
             _lib.check(lib.y3_set_conv_tile(tile))
             outs[tile] = gpu_util.run_conv(x, k, b, 1, "bf16", leaky=True, residual=r)
             assert np.all(np.abs(outs[tile] - want) <= 1e-2 * np.maximum(1.0, np.abs(want))), tile
-    finally:
-        lib.y3_set_conv_tile(0)
     np.testing.assert_array_equal(outs[0], outs[64])
     np.testing.assert_array_equal(outs[0], outs[261])
+    np.testing.assert_array_equal(outs[0], gpu_util.run_conv(x, k, b, 1, "bf16", leaky=True, residual=r))    # product library
 
 
 @pytest.mark.parametrize("case", ["ring_ups", "ring_1x1_res", "head_f32_256tile"])

@@ -32,30 +32,82 @@ def _mask_to_dense(rec, C=80):
     return out
 
 
-@pytest.mark.parametrize("grids,anchors,size,image_shape", [
-    ((13, 26, 52), COCO, 416, (416, 416)),
-    ((19, 38, 76), COCO, 608, (375, 500)),
-    ((13, 26), TINY, 416, (720, 1280)),
+def _oracle_class_mask(heads_b, anchors, size):
+    """utils/utils.py:150-151 through the oracle: mask = (cls >= max_c cls) on its fp32 sigmoids, pooled coarse -> fine."""
+    out = []
+    for l, h in enumerate(heads_b):
+        cls = odec.get_head(h, anchors[odec.anchor_masks(len(heads_b))[l]], 80, (size, size))[3]
+        out.append((cls >= cls.max(axis=-1, keepdims=True)).reshape(-1, 80))
+    return np.concatenate(out)
+
+
+def _robust_zones(heads_b):
+    """Where the class mask does not depend on the last ulp of expf: `must` = classes tied with the maximum for
+    any correct sigmoid (same logit as the largest, or both saturated: t > 18.1 gives 1/(1+e) == 1.0f whatever the
+    last bits of e), `mustnt` = classes whose float64 sigmoid is more than 1e-6 (relative) below the maximum."""
+    t = np.concatenate([h.reshape(-1, 85)[:, 5:] for h in heads_b]).astype(np.float64)
+    tmax = t.max(axis=1, keepdims=True)
+    with np.errstate(over="ignore"):
+        p = 1.0 / (1.0 + np.exp(-t))
+    pmax = p.max(axis=1, keepdims=True)
+    must = (t == tmax) | ((t > 18.1) & (tmax > 18.1)) | ((t < -104.0) & (tmax < -104.0))
+    mustnt = p < pmax * (1.0 - 1e-6)
+    return must, mustnt
+
+
+@pytest.mark.parametrize("grids,anchors,size,image_shape,ld,scale", [
+    ((13, 26, 52), COCO, 416, (416, 416), 255, 1.5),
+    ((19, 38, 76), COCO, 608, (375, 500), 255, 1.5),
+    ((13, 26), TINY, 416, (720, 1280), 255, 1.5),
+    # cells 256 floats apart = what the network hands y3_decode: the lane-per-box LDS-DMA kernel, directly against the oracle
+    ((19, 38, 76), COCO, 608, (375, 500), 256, 1.5),
+    ((13, 26), TINY, 416, (720, 1280), 256, 1.5),
+    ((13, 26, 52), COCO, 416, (300, 500), 256, 12.0),     # saturated sigmoids: many classes tie at 1.0
+    ((13, 26, 52), COCO, 416, (300, 500), 255, 12.0),
 ])
-def test_fused_decode_matches_oracle(grids, anchors, size, image_shape):
-    rng = np.random.default_rng(size + len(grids))
+def test_fused_decode_matches_oracle(grids, anchors, size, image_shape, ld, scale):
+    rng = np.random.default_rng(size + len(grids) + ld + int(scale))
     B = 3
-    heads = _heads(rng, B, grids)
+    full = [(rng.standard_normal((B, g, g, ld)) * scale).astype(np.float32) for g in grids]
+    if scale > 10:
+        full[0][0, 0, 0, 5:85] = -110.0                      # every class underflows: all tie at sigmoid == 0
+        full[0][0, 0, 0, 4] = 3.0
+        full[1][1, 2, 3, 90:170] = 30.0                      # every class saturates: all tie at 1
+        full[1][1, 2, 3, 89] = 3.0
+    heads = [f[..., :255] for f in full]
     pp = PostProcessor(anchors, 80, (size, size), score_threshold=0.3)
-    det = pp([torch.from_numpy(h).cuda() for h in heads], image_shape)
+    dev_heads = [torch.from_numpy(f).cuda()[..., :255] for f in full]
+    det = pp(dev_heads, image_shape)
     torch.cuda.synchronize()
+    assert pp.prepare(dev_heads, image_shape)[1].head_ld[0] == ld          # the layout under test reached the library
     rec = det.records.cpu().numpy()
     cand_count = det.cand_count.cpu().numpy()
+    loose = total = 0
     for b in range(B):
-        boxes, scores = odec.pooled_boxes_and_scores([h[b:b + 1] for h in heads], anchors, 80, (size, size), image_shape)
+        hb = [h[b:b + 1] for h in heads]
+        with np.errstate(over="ignore"):
+            boxes, scores = odec.pooled_boxes_and_scores(hb, anchors, 80, (size, size), image_shape)
+            want_mask = _oracle_class_mask(hb, anchors, size)
         np.testing.assert_allclose(rec[b, :, :4], boxes, rtol=1e-5, atol=1e-4)
         best = scores.max(axis=1)
         np.testing.assert_allclose(rec[b, :, 4], best, rtol=0, atol=2e-6)
-        top2 = np.sort(np.concatenate([h[b].reshape(-1, 85)[:, 5:] for h in heads]), axis=1)[:, -2:]
-        clear = (top2[:, 1] - top2[:, 0]) > 1e-4
-        np.testing.assert_array_equal(_mask_to_dense(rec[b])[clear], (scores > 0)[clear])
+        got_mask = _mask_to_dense(rec[b])
+        must, mustnt = _robust_zones(hb)
+        assert got_mask[must].all() and not got_mask[mustnt].any()
+        np.testing.assert_array_equal(want_mask[must | mustnt], got_mask[must | mustnt])
+        # elsewhere (sigmoids within 1e-6 of the largest but not provably tied) the two expf implementations may
+        # round differently: counted, and required to be rare
+        loose += int((want_mask != got_mask).sum())
+        total += want_mask.size
         n_or = int((best >= np.float32(0.3)).sum())
         assert abs(int(cand_count[b]) - n_or) <= 2          # borderline scores may flip by an ulp
+    print("decode ld=%d scale=%g: %d of %d class-mask bits differ from the oracle (near-ties only)" % (ld, scale, loose, total))
+    assert loose <= 1e-4 * total
+    if scale > 10:
+        p0 = 0                                              # scale 0, cell (0,0), anchor 0: all 80 classes tie at 0
+        assert _mask_to_dense(rec[0])[p0].all() and rec[0, p0, 4] == 0.0
+        p1 = 13 * 13 * 3 + (2 * 26 + 3) * 3 + 1             # scale 1, cell (2,3), anchor 1: all tie at 1
+        assert _mask_to_dense(rec[1])[p1].all() and rec[1, p1, 4] == np.float32(1.0) / (np.float32(1.0) + np.exp(np.float32(-3.0)))
 
 
 def test_decode_known_answers_on_gpu():
@@ -113,7 +165,6 @@ def test_lane_per_box_decode_equals_16_lane_decode(grids, anchors, size, scale):
     16-lanes-per-box kernel bit for bit -- records, candidate set and per-class counts -- including
     saturated sigmoids (scale 12: many classes tie at 1.0) and underflowing ones (scale 60)."""
     from yolo_amd import _lib
-    lib = _lib.load()
     rng = np.random.default_rng(int(size + scale))
     B = 2
     full = [torch.from_numpy((rng.standard_normal((B, g, g, 256)) * scale).astype(np.float32)).cuda() for g in grids]
@@ -122,7 +173,7 @@ def test_lane_per_box_decode_equals_16_lane_decode(grids, anchors, size, scale):
         full[1][1, 2, 3, 90:170] = 30.0                      # every class saturates: all tie at 1
     heads = [t[..., :255] for t in full]
     outs = []
-    try:
+    with _lib.experimental() as lib:          # libyolo3hip_exp.so: the product library has no variant switch
         for variant in (1, 0):
             lib.y3_decode_variant(variant)
             pp = PostProcessor(anchors, 80, (size, size), score_threshold=0.3)
@@ -133,8 +184,6 @@ def test_lane_per_box_decode_equals_16_lane_decode(grids, anchors, size, scale):
             cand = [np.sort(ws["cand_idx"][b, :n[b]].cpu().numpy()) for b in range(B)]
             outs.append((det.records.cpu().numpy().copy(), n.copy(), cand, ws["counts"].cpu().numpy().copy(),
                          det.kept_idx.cpu().numpy().copy(), det.kept_count.cpu().numpy().copy()))
-    finally:
-        lib.y3_decode_variant(0)
     a, b_ = outs
     np.testing.assert_array_equal(a[0].view(np.uint32), b_[0].view(np.uint32))
     np.testing.assert_array_equal(a[1], b_[1])

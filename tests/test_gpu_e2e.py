@@ -39,6 +39,22 @@ def _dense_from_records(rec, C=80):
     return rec[:, :4], scores
 
 
+def bf16_error_figures(h, r):
+    """Error figures of one bf16-mode head tensor against an oracle tensor.  `norm` is the north_star's "2e-2
+    relative" as this suite reads it (max-abs error / max-abs reference); the other two are element-wise, so that
+    the leniency of the normalised reading is on record: `elem_max` = max |err| / max(|ref|, 1) and
+    `frac_over` = share of elements with |err| > 2e-2 * max(|ref|, 1).  Measured: the
+    element-wise reading does NOT hold end to end (bf16 storage through 75 layers: elem_max ~5e-2, 2-4 percent of
+    the elements over 2e-2), neither against the fp32 oracle nor against its bf16-storage model; launch by launch
+    (tests/test_gpu_layerwise.py) every kernel is within one bf16 ulp of that model."""
+    h = np.asarray(h, dtype=np.float64)
+    r = np.asarray(r, dtype=np.float64)
+    err = np.abs(h - r)
+    den = np.maximum(np.abs(r), 1.0)
+    return {"norm": float(err.max() / np.abs(r).max()), "elem_max": float((err / den).max()),
+            "frac_over": float((err > 2e-2 * den).mean())}
+
+
 def _check_nms_exact(det, b, thr):
     boxes, scores = _dense_from_records(det.records[b].cpu().numpy())
     ob, os_, oc = odec.select(boxes, scores, thr, config.nms_threshold, config.max_boxes)
@@ -99,6 +115,15 @@ def test_yolov3_416_heads(dtype):
             assert err <= 1e-3
         else:
             assert err / np.abs(r).max() <= 2e-2
+            print("yolov3-416 bf16 head %s vs fp32 oracle: %s" % (tuple(r.shape), bf16_error_figures(h.cpu().numpy(), r)))
+    if dtype == "bf16":
+        # against the oracle's bf16-storage model the figures are the same size: end to end the two runs carry
+        # independent realisations of the same rounding noise (tests/test_gpu_layerwise.py is the launch-by-launch
+        # check that the kernels themselves are within one bf16 ulp of that model)
+        for h, r in zip(heads, od.forward_bf16_model(layers, oi, params, x)):
+            fig = bf16_error_figures(h.cpu().numpy(), r)
+            print("yolov3-416 bf16 head %s vs bf16-storage oracle: %s" % (tuple(r.shape), fig))
+            assert fig["norm"] <= 2e-2
     anchors = inference.read_anchors(config.anchors_path)
     det = inference.predict_batch(heads, anchors, 80, (416, 416), (416, 416))
     for b in range(2):
@@ -146,6 +171,50 @@ def test_full_size_properties_608_bf16():
     m0 = _check_nms_exact(det, 0, config.score_threshold)
     m9 = _check_nms_exact(det, 9, config.score_threshold)
     assert m0 == m9 > 0 and torch.equal(det.boxes[0, :m0], det.boxes[9, :m9])
+
+
+def test_headline_shape_608_bf16_batch64():
+    """The bench configuration itself (YOLOv3-608, bf16, 64 images: a 2.27 GB arena, buffer offsets near 2^31 in
+    the register epilogue).  Image 0 is repeated at position 63 and image 1 at 37: heads and detections must be bit-equal
+    between the copies and equal to the batch-1 runs, whose heads are checked against the oracle (normalised and
+    element-wise bf16 figures); NMS of images 0, 37 and 63 equals the oracle's NMS of the same decoded boxes."""
+    nodes, layers, oi, params = _net(config.yolov3_cfg_path, "bf16", 15)
+    gen = torch.Generator(device="cpu").manual_seed(15)
+    x = torch.rand((64, 608, 608, 3), generator=gen, dtype=torch.float32)
+    x[63] = x[0]
+    x[37] = x[1]
+    xt = x.cuda()
+    heads = [h.clone() for h in nodes(xt)]
+    assert [tuple(h.shape) for h in heads] == [(64, 19, 19, 255), (64, 38, 38, 255), (64, 76, 76, 255)]
+    for h in heads:
+        assert torch.equal(h[0], h[63]) and torch.equal(h[1], h[37])
+        assert bool(torch.isfinite(h).all())
+    anchors = inference.read_anchors(config.anchors_path)
+    det = inference.predict_batch(heads, anchors, 80, (608, 608), (608, 608))
+    counts = det.count.cpu().numpy().copy()
+    det_rows = {b: tuple(t.clone() for t in det.image(b)) for b in (0, 1, 37, 63)}
+    for b in (0, 37, 63):
+        assert _check_nms_exact(det, b, config.score_threshold) == counts[b]
+    assert counts[0] == counts[63] > 0 and counts[1] == counts[37]
+    for a, b in ((0, 63), (1, 37)):
+        for u, v in zip(det_rows[a], det_rows[b]):
+            assert torch.equal(u, v)
+    for b in (0, 1):                                   # the same image alone: same bits (heads and detections)
+        one = [h.clone() for h in nodes(xt[b:b + 1])]
+        for h, o in zip(heads, one):
+            assert torch.equal(h[b:b + 1], o)
+        d1 = inference.predict_batch(one, anchors, 80, (608, 608), (608, 608))
+        for u, v in zip(d1.image(0), det_rows[b]):
+            assert torch.equal(u, v)
+    ref = od.forward(layers, oi, params, x[:1].numpy())
+    for h, r in zip(heads, ref):
+        fig = bf16_error_figures(h[:1].cpu().numpy(), r)
+        print("yolov3-608 b64 bf16 head %s vs fp32 oracle: %s" % (tuple(r.shape), fig))
+        assert fig["norm"] <= 2e-2
+    for h, r in zip(heads, od.forward_bf16_model(layers, oi, params, x[:1].numpy())):
+        fig = bf16_error_figures(h[:1].cpu().numpy(), r)
+        print("yolov3-608 b64 bf16 head %s vs bf16-storage oracle: %s" % (tuple(r.shape), fig))
+        assert fig["norm"] <= 2e-2
 
 
 def test_dense_stress_config5():

@@ -1,0 +1,92 @@
+"""-m gpu: every launch of the real bf16 plans against the oracle's bf16-storage model, TEACHER-FORCED.
+
+End to end, a bf16 run and the oracle's bf16-storage model of the same graph (oracle.darknet.forward_bf16_model)
+decorrelate: a last-bit difference in one fp32 sum flips a bf16 rounding, the flip changes the next layer's sums, and
+within a few layers the two runs carry independent realisations of the same rounding noise (measured: GPU vs model
+8.5e-3 normalised, GPU vs the fp32 graph 9.1e-3 -- DESIGN.md section 5).  That says the error is bf16 storage, but it
+cannot show that each kernel is right.  This test can: after every launch the tensor it wrote is compared with the
+model's tensor for that layer and then OVERWRITTEN with it, so every launch runs on exactly the model's inputs and may
+differ from the model only by fp32 summation order -- at most one bf16 ulp of the value (2^-7 relative), on few
+elements.  Covers the fused stem, residual epilogues, 2x2 upsampling stores, zero-copy concat slices and the fp32 heads
+at their real shapes, strides and weights."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import darknet as od
+from yolo_amd import build_model, config
+from yolo_amd import darknet_weights as dw
+
+pytestmark = pytest.mark.gpu
+
+
+def _view(cp, ref, heads, B, hw, dtype):
+    """torch view [B*h*w, c] of a plan tensor reference (arena or head)."""
+    n = B * hw[0] * hw[1]
+    if ref["buf"][0] == "arena":
+        base = cp.arena[ref["buf"][1]:].view(dtype)
+    else:
+        base = heads[ref["buf"][1]].reshape(-1)
+    # (as_strided's offset is absolute in the storage, not relative to `base`)
+    return torch.as_strided(base, (n, ref["c"]), (ref["ld"], 1), base.storage_offset() + ref["off"])
+
+
+@pytest.mark.parametrize("cfg_name,size,batch", [("yolov3", 160, 2), ("yolov3", 608, 1), ("yolov3-tiny", 416, 2), ("yolov3-spp", 160, 1)])
+def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch):
+    cfg = {"yolov3": config.yolov3_cfg_path, "yolov3-tiny": config.yolov3_tiny_cfg_path, "yolov3-spp": config.yolov3_spp_cfg_path}[cfg_name]
+    layers, oi = od.parse_layers(cfg, 80)
+    params = dw.random_params(layers, seed=31)
+    x = np.random.default_rng(31).random((batch, size, size, 3), dtype=np.float32)
+    net = build_model.Network(cfg, 80, dtype="bf16")
+    net.set_params(params)
+    cp = net.plan_for(batch, size, size)
+    has_stem = cp.plan.ops[0]["kind"] == "stem"          # otherwise the 3-channel first layer runs in fp32 (direct kernel)
+    _, model = od.forward_bf16_model(layers, oi, params, x, collect=True, first_conv_fp32=not has_stem)
+    xt = torch.from_numpy(x).cuda()
+    heads = [torch.zeros((batch, hd["h"], hd["w"], hd["ld"]), dtype=torch.float32, device="cuda") for hd in cp.plan.heads]
+    env = {"in": xt.data_ptr(), "stream": torch.cuda.current_stream().cuda_stream, "heads": [h.data_ptr() for h in heads]}
+    from yolo_amd import _lib
+    checked = flipped = total = 0
+    worst = 0.0
+    for op, launch in zip(cp.plan.ops, cp.launchers):
+        _lib.check(launch(env))
+        torch.cuda.synchronize()
+        outs = []            # (reference key, layer whose tensor it is)
+        if op["kind"] == "stem":
+            outs.append(("y", op["layers"][1]))
+            if op.get("y2") is not None:
+                outs.append(("y2", op["layers"][2]))
+        elif op["kind"] == "conv":
+            outs.append(("y", op["writes_layer"]))
+        elif op["kind"] in ("maxpool", "upsample", "add"):
+            outs.append(("y", op["layer"]))
+        else:
+            continue
+        for key, li in outs:
+            want = model[li]
+            hw = want.shape[1:3]
+            f32 = op["kind"] == "conv" and op["out_f32"]
+            v = _view(cp, op[key], heads, batch, hw, torch.float32 if f32 else torch.bfloat16)
+            got = v.float().cpu().numpy().reshape(want.shape)
+            err = np.abs(got - want)
+            if f32:          # head tensors: fp32 sums of identical bf16 products, other order
+                assert np.all(err <= 1e-4 * np.maximum(1.0, np.abs(want))), "layer %d (head)" % li
+            else:
+                # bf16 tensors: the same value or its bf16 neighbour (2^-7 relative), plus what a different fp32
+                # summation order moves a value that is small against its own terms.  The stem's conv B / C run
+                # on conv A's / conv B's output inside the launch, which cannot be forced: one flipped input there
+                # (one bf16 ulp of a value of a few units) times a weight moves an output by up to ~1 ulp of the
+                # tensor's largest value, hence the wider absolute term for the stem's two tensors.
+                big = max(1.0, float(np.abs(want).max()))
+                floor = 2.0 ** -7 * big if op["kind"] == "stem" else 4e-6 * big
+                assert np.all(err <= np.abs(want) * 2.0 ** -7 + floor), "layer %d: more than one bf16 ulp" % li
+                flipped += int((err > 0).sum())
+                total += err.size
+                v.copy_(torch.from_numpy(want.reshape(-1, want.shape[-1])).cuda().to(torch.bfloat16))     # teacher forcing
+            worst = max(worst, float((err / np.maximum(np.abs(want), 1e-3)).max()))
+            checked += 1
+    n_conv = sum(1 for L in layers if L["type"] == "conv")
+    assert checked >= n_conv - 1                     # every convolution's tensor (the stem writes two of three)
+    print("%s %d b%d: %d tensors checked, %d of %d bf16 elements off by one ulp (%.2e), worst relative %.2e"
+          % (cfg_name, size, batch, checked, flipped, total, flipped / max(total, 1), worst))
+    assert flipped <= 2e-3 * total

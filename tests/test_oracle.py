@@ -243,3 +243,51 @@ def test_oracle_reproduces_committed_config1_fixture():
     np.testing.assert_array_equal(got["classes"], want["classes"])
     np.testing.assert_allclose(got["boxes"], want["boxes"], rtol=0, atol=1e-2)
     np.testing.assert_allclose(got["scores"], want["scores"], rtol=0, atol=1e-5)
+
+
+def test_bf16_storage_model_is_close_to_fp32_graph():
+    """oracle.darknet.forward_bf16_model (bf16 weights + activations, fp32 sums: what the build's bf16 mode computes)
+    stays within the north_star's 2e-2 (max-abs / max-abs) of the fp32 graph, and differs from it (it is a model of
+    bf16 storage, not a copy of `forward`)."""
+    from yolo_amd import config, darknet_weights as dw
+    layers, oi = od.parse_layers(config.yolov3_tiny_cfg_path, 80)
+    params = dw.random_params(layers, seed=3)
+    x = np.random.default_rng(3).random((1, 96, 96, 3), dtype=np.float32)
+    ref = od.forward(layers, oi, params, x)
+    mod = od.forward_bf16_model(layers, oi, params, x)
+    for r, m in zip(ref, mod):
+        err = np.abs(r - m).max() / np.abs(r).max()
+        assert 0 < err <= 2e-2
+    a = np.array([1.0, 1.00390625, 1.005859375, -3.1415927, 0.0], dtype=np.float32)
+    np.testing.assert_array_equal(od.bf16_round(a), np.array([1.0, 1.0, 1.0078125, -3.140625, 0.0], dtype=np.float32))
+
+
+def test_one_by_one_stride_two_is_refused():
+    """the reference pads top/left for any stride > 1 (build_model.py:151-154); a 1x1 stride-2 conv is not
+    implemented that way, so the planner refuses it instead of computing something else."""
+    import pytest
+    from yolo_amd import planner
+    layers = [dict(type="conv", conv_idx=0, cin=8, filters=8, size=1, stride=2, pad=0, bn=True, activation="leaky", same=False)]
+    with pytest.raises(ValueError, match="1x1 conv with stride"):
+        planner.infer_shapes(layers, 16, 16, 8)
+
+
+def test_weights_file_with_trailing_floats_warns(tmp_path):
+    """a .weights file written for a larger network loads its prefix -- with a warning, not silently."""
+    import pytest
+    from yolo_amd import config, darknet_weights as dw, planner
+    layers = planner.parse_cfg(config.yolov3_tiny_cfg_path, 80)[0]
+    params = dw.random_params(layers, seed=0)
+    path = str(tmp_path / "w.weights")
+    dw.write_weights(path, layers, params)
+    with open(path, "ab") as fp:
+        np.zeros(7, dtype=np.float32).tofile(fp)
+    with pytest.warns(RuntimeWarning, match="floats consumed"):
+        dw.read_weights(path, layers)
+
+
+def test_global_variables_tracks_live_networks_only():
+    import gc
+    from yolo_amd import build_model
+    build_model.reset_default_graph()
+    assert build_model.global_variables() == []

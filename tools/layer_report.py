@@ -28,9 +28,11 @@ def main():
     a = ap.parse_args()
     cfg = config.yolov3_tiny_cfg_path if a.model == "yolov3-tiny" else config.yolov3_cfg_path
     from yolo_amd import _lib
-    _lib.check(_lib.load().y3_set_conv_tile(a.tile))
-    if a.phase >= 0:
-        _lib.check(_lib.load().y3_set_conv_phase(a.phase))
+    if a.tile or a.phase >= 0:           # overrides exist only in libyolo3hip_exp.so (-DY3_EXPERIMENTS)
+        _lib._lib = _lib.load_experimental()
+        _lib.check(_lib.load().y3_set_conv_tile(a.tile))
+        if a.phase >= 0:
+            _lib.check(_lib.load().y3_set_conv_phase(a.phase))
     net = build_model.Network(cfg, 80, dtype=a.dtype, stem=not a.no_stem, splitk=a.splitk)
     net.set_params(dw.random_params(net.layers, seed=0))
     x = torch.rand((a.batch, a.size, a.size, 3), device="cuda")

@@ -5,6 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOLO3HIP_LIB") or os.path.join(_HERE, "libyolo3hip.so")     # override: A/B builds
+EXP_LIB_PATH = os.path.join(_HERE, "libyolo3hip_exp.so")       # -DY3_EXPERIMENTS flavour: tests and A/B tools only
 
 Y3_F32, Y3_BF16 = 0, 1
 CONV_LEAKY, CONV_RESIDUAL, CONV_UPS2X, CONV_OUT_F32, CONV_IN_F32, CONV_REVERSE, CONV_POOL2 = 1, 2, 4, 8, 16, 32, 64
@@ -39,15 +40,11 @@ SIGNATURES = {
     "y3_conv2d_splitk": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, c_vp]),
     "y3_conv_stem": (c_int, [ctypes.POINTER(StemDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "y3_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_int]),
-    "y3_set_conv_tile": (c_int, [c_int]),
-    "y3_set_conv_phase": (c_int, [c_int]),
-    "y3_set_conv_cus": (c_int, [c_int]),
     "y3_maxpool2d": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "y3_upsample2x": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "y3_copy_channels": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
     "y3_shortcut_add": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp]),
     "y3_decode": (c_int, [ctypes.POINTER(DecodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "y3_decode_variant": (c_int, [c_int]),
     "y3_get_head": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32, c_f32,
                             c_vp, c_vp, c_vp, c_vp, c_vp]),
     "y3_correct_boxes": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp]),
@@ -65,26 +62,71 @@ SIGNATURES = {
     "y3_last_error": (ctypes.c_char_p, []),
 }
 
+# include/yolo3hip_experimental.h: only libyolo3hip_exp.so exports these
+EXPERIMENTAL_SIGNATURES = {
+    "y3_set_conv_tile": (c_int, [c_int]),
+    "y3_set_conv_phase": (c_int, [c_int]),
+    "y3_set_conv_cus": (c_int, [c_int]),
+    "y3_decode_variant": (c_int, [c_int]),
+}
+
 _lib = None
+_exp = None
+
+
+def _open(path, signatures):
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C yolo_amd/csrc` (there is no CPU fallback)" % path)
+    # torch first: it brings its own HIP runtime (libamdhip64), and the library must bind to that one.
+    # Loaded before torch, libyolo3hip.so pulls the system runtime in and every launch then fails with
+    # "no ROCm-capable device is detected".
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
 
 
 def load():
     """Load the HIP library; raise (never fall back) if it is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                               "or `make -C yolo_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
-        # torch first: it brings its own HIP runtime (libamdhip64), and the library must bind to that one.
-        # Loaded before torch, libyolo3hip.so pulls the system runtime in and every launch then fails with
-        # "no ROCm-capable device is detected".
-        import torch  # noqa: F401
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
-        _lib = lib
+        _lib = _open(LIB_PATH, SIGNATURES)
     return _lib
+
+
+def load_experimental():
+    """libyolo3hip_exp.so: the same kernels built with -DY3_EXPERIMENTS, plus the tile / variant setters.
+    For the kernel-variant tests and the A/B tools; the product path never loads it."""
+    global _exp
+    if _exp is None:
+        sig = dict(SIGNATURES)
+        sig.update(EXPERIMENTAL_SIGNATURES)
+        _exp = _open(EXP_LIB_PATH, sig)
+    return _exp
+
+
+class experimental(object):
+    """`with _lib.experimental() as lib:` -- inside the block every `_lib.load()` (hence the whole Python
+    surface: Network, PostProcessor, ...) runs on the experimental flavour; knobs are reset on exit."""
+
+    def __enter__(self):
+        global _lib
+        self._saved = _lib
+        _lib = load_experimental()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        lib = _lib
+        lib.y3_set_conv_tile(0)
+        lib.y3_set_conv_phase(50)
+        lib.y3_set_conv_cus(0)
+        lib.y3_decode_variant(0)
+        _lib = self._saved
+        return False
 
 
 class Y3Error(RuntimeError):

@@ -14,7 +14,9 @@ the reference's `yolo()` hands to `predict()`.
 torch is used for device memory and streams only; all arithmetic is in libyolo3hip.so.
 """
 import ctypes
+import itertools
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -23,13 +25,18 @@ from . import _lib, config, planner
 from . import darknet_weights as dw
 from .planner import unique_config_sections  # noqa: F401  (re-exported: reference API)
 
-_NETWORKS = []          # what tf.global_variables() is to the reference's load_weights call
+_NETWORKS = weakref.WeakSet()   # what tf.global_variables() is to the reference's load_weights call: the networks that
+                                # are still alive (a dropped Network frees its device weights and plan arenas)
+_ORDER = weakref.WeakKeyDictionary()   # creation order, for a stable global_variables() listing
+
+
+_COUNTER = itertools.count()
 
 
 def global_variables():
     """Stand-in for tf.global_variables() in `load_weights(tf.global_variables(), path)`
     (inference.py:255): the networks built so far."""
-    return list(_NETWORKS)
+    return sorted(_NETWORKS, key=lambda n: _ORDER.get(n, 0))
 
 
 def _dtype_code(dtype):
@@ -361,8 +368,15 @@ def yolo(input_images, is_training, config_path, num_classes, dtype=None, device
     if is_training:
         raise ValueError("yolo_amd implements the inference path only: is_training must be False")
     net = Network(config_path, num_classes, dtype=dtype, device=device, splitk=splitk)
-    _NETWORKS.append(net)
+    _NETWORKS.add(net)
+    _ORDER[net] = next(_COUNTER)
     return OutputNodes(net)
+
+
+def reset_default_graph():
+    """tf.reset_default_graph() for this package: forget every network yolo() has built (they are freed once the
+    caller drops its own references)."""
+    _NETWORKS.clear()
 
 
 class _LoadOp(object):

@@ -21,7 +21,9 @@
 // from pointing the lane's source address at a zero page.
 //
 // What runs by default (conv_variant picks per layer; everything else below is a measured alternative that no
-// layer selects, reachable through y3_set_conv_tile for A/B runs -- results in DESIGN.md section 3.1):
+// layer selects, reachable only in the -DY3_EXPERIMENTS flavour of the library (libyolo3hip_exp.so,
+// include/yolo3hip_experimental.h: y3_set_conv_tile) for A/B runs and the tile-equality tests -- results in
+// DESIGN.md section 3.1.  The default library has no knob, no process-global state and none of the timing paths):
 //   256  conv_igemm_kernel<256,256, 8 waves>   Cout >= 256, few rounds         persistent, register epilogue
 //   192  conv_igemm_kernel<192,256, 8 waves>   same, when it saves a round     persistent, register epilogue
 //   257  conv_igemm_ring_kernel<256,128,RING 3> 65..128 output channels (bf16)  two workgroups per CU
@@ -29,8 +31,8 @@
 //   128 / 64 / 32  conv_igemm_kernel<128,BN>   small layers, fp32 mode         2-3 workgroups per CU
 //   direct  conv_direct_kernel                 Cin = 3 (first layer) when the fused stem is not used
 // Alternatives: 129 (128x256), 258 (256x128, 8 waves), 130/131 (128x128 ring), debug bit 4 (ring for 256/128).
-// Debug bits (high half of y3_set_conv_tile): 1/8/16/32 timing experiments that skip loads or the epilogue
-// (results are garbage), 2 no interleave, 64 force the LDS epilogue, 128 one workgroup per tile.
+// Debug bits (high half of y3_set_conv_tile, Y3_EXPERIMENTS only): 1/8/16/32 timing experiments that skip loads or
+// the epilogue (results are garbage), 2 no interleave, 64 force the LDS epilogue, 128 one workgroup per tile.
 // Compile-time switches, default off because they measured slower: Y3_XPF (cross-tile prefetch),
 // Y3_STORE_AUX / Y3_RES_AUX (cache policy of the epilogue's stores and residual loads).
 #include "common.h"
@@ -38,10 +40,39 @@
 
 namespace {
 
-int g_conv_tile = 0;      // experiment knobs, see y3_set_conv_tile
-int g_conv_debug = 0;
-int g_conv_cus = 256;               // CUs a launch may occupy (experiment knob: y3_set_conv_cus)
+#ifdef Y3_EXPERIMENTS
+// Experiment knobs of libyolo3hip_exp.so (include/yolo3hip_experimental.h): plain process-global state, set by
+// one thread between launches -- a test and measurement facility, not part of the product library.
+int g_conv_tile = 0;                // forced tile, see y3_set_conv_tile
+int g_conv_debug = 0;               // its high half: debug bits
+int g_conv_cus_cap = 0;             // CUs a launch may occupy (0 = all of the device's: y3_set_conv_cus)
 int g_conv_phase_pct = 50;          // start offset of the de-phased workgroups, percent of a tile period (0 = off)
+#else
+constexpr int g_conv_tile = 0, g_conv_debug = 0, g_conv_cus_cap = 0, g_conv_phase_pct = 50;
+#endif
+
+// Compute units of the current device (MI355X: 256; fewer in a partitioned mode), queried once per device.
+// Sizes the persistent grids, the de-phasing condition and the wave-quantisation model of conv_variant.
+int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int slot = dev >= 0 && dev < 64 ? dev : 0;
+    int v = __atomic_load_n(&cached[slot], __ATOMIC_RELAXED);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
+            (void)hipGetLastError();
+            v = 256;
+        }
+        __atomic_store_n(&cached[slot], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
+
+int conv_cus() {
+    const int cus = device_cus();
+    return g_conv_cus_cap > 0 && g_conv_cus_cap < cus ? g_conv_cus_cap : cus;
+}
 
 struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
 
@@ -427,12 +458,14 @@ void conv_igemm_kernel(const ConvArgs p) {
         cin = wrap ? cin - p.Cin : cin;
         tap = wrap ? tap + 1 : tap;
     };
-    // (the uniform branch these two experiment flags put around every piece is worth keeping: compiled out, the
-    // scheduler packs the pieces differently and the network runs 1 % slower)
-    const bool skip_a = p.flags & (1 << 29), skip_b = p.flags & (1 << 28);
+#ifdef Y3_EXPERIMENTS
+    const bool skip_a = p.flags & (1 << 29), skip_b = p.flags & (1 << 28);      // timing experiments: pieces not issued
+#endif
     auto piece = [&](int q, int kt, int buf) {
         char *base = smem + buf * STAGE + wave * 1024;
+#ifdef Y3_EXPERIMENTS
         if (q < A_IT ? skip_a : skip_b) return;
+#endif
         if (q < A_IT) {
             const char *cand = p.in + (a_base[q] + toff);
             const char *src = ((a_mask[q] >> tapc) & 1u) ? cand : p.zeros;
@@ -483,6 +516,29 @@ void conv_igemm_kernel(const ConvArgs p) {
 
     // residual pieces the last k-step fetches ahead of the epilogue (register epilogue only)
     constexpr int RES_EARLY = (BF16 && NI % 2 == 0 && MI * NI * 4 <= 96) ? (MI * (NI / 2) * Y3_RES_EARLY_16THS) / 16 : 0;
+    using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
+    auto mfma_group = [&](int j, const frag_t (&xq)[MI], const frag_t (&wq)[NI]) {
+        const int ni = j / MI, mi = j % MI;
+        if constexpr (BF16) {
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ni], xq[mi], acc[ni][mi], 0, 0, 0);
+        } else {
+            // lane group g holds k = 4g..4g+3 of this 16-wide k block: MFMA i sums k = 4g+i over g.
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[ni][i], xq[mi][i], acc[ni][mi], 0, 0, 0);
+        }
+    };
+    // piece q of the next k-step goes before MFMA group J0 + floor(q * NJ / NP), NJ = NMF - J0: the first J0 groups carry
+    // no piece (and no scheduling barrier), so that they can start while the later fragment reads are still in flight
+    auto pieces_before = [&](int j, int kt) {
+        constexpr int NJ = NMF - J0;
+#pragma unroll
+        for (int q = j < J0 ? NP : ((j - J0) * NP + NJ - 1) / NJ; q < ((j - J0 + 1) * NP + NJ - 1) / NJ; ++q) {
+            if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+            piece(q, kt + 1, pb ^ 1);
+            if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto kstep = [&](int kt, auto prefetch, auto early) {
         constexpr bool PF = decltype(prefetch)::value;
         // this wave's LDS-DMA of k-step kt has landed (after a cross-tile prefetch the epilogue's stores may remain)
@@ -497,7 +553,6 @@ void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int so = ((ks * 4 + fq) ^ fsw) * 16;
-            using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
             frag_t xf[MI], wf[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -508,34 +563,13 @@ void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int j = 0; j < NMF; ++j) {
                 if constexpr (PF) {
-                    if (ks == 0) {
-                        // piece q goes before MFMA group J0 + floor(q * NJ / NP), NJ = NMF - J0: the first J0 groups carry
-                        // no piece (and no scheduling barrier), so that they can start while the later fragment reads
-                        // of this half-step are still in flight
-                        constexpr int NJ = NMF - J0;
-#pragma unroll
-                        for (int q = j < J0 ? NP : ((j - J0) * NP + NJ - 1) / NJ; q < ((j - J0 + 1) * NP + NJ - 1) / NJ; ++q) {
-                            if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
-                            piece(q, kt + 1, pb ^ 1);
-                            if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
+                    if (ks == 0) pieces_before(j, kt);
                 }
-                const int ni = j / MI, mi = j % MI;
-                if constexpr (BF16) {
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-                } else {
-                    // lane group g holds k = 4g..4g+3 of this 16-wide k block: MFMA i sums k = 4g+i over g.
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][i], xf[mi][i], acc[ni][mi], 0, 0, 0);
-                }
+                mfma_group(j, xf, wf);
             }
         }
         pb ^= 1;
     };
-
-    for (int kt = kt0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, [] {});
     u32x4 rv[MI][NI % 2 == 0 ? NI / 2 : 1];
     auto res_early = [&] {
         if constexpr (RES_EARLY > 0) {
@@ -545,6 +579,7 @@ void conv_igemm_kernel(const ConvArgs p) {
             }
         }
     };
+    for (int kt = kt0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, [] {});
     const int next_tile = tile + (int)gridDim.x;
     primed = XPF_OK && reg_epi && p.splits <= 1 && next_tile < p.total_tiles && !(p.flags & ((1 << 27) | (1 << 25)));
     if (primed) {
@@ -558,6 +593,7 @@ void conv_igemm_kernel(const ConvArgs p) {
         kstep(nk - 1, std::false_type{}, res_early);
     }
 
+#ifdef Y3_EXPERIMENTS
     if (p.flags & (1 << 27)) {          // timing experiment: no epilogue (one store keeps the accumulators live)
         float sacc = 0.f;
 #pragma unroll
@@ -568,6 +604,7 @@ void conv_igemm_kernel(const ConvArgs p) {
         if (sacc == 123.456f) *(float *)p.out = sacc;
         continue;
     }
+#endif
     if constexpr (BF16) {
         if (reg_epi) {
             conv_epilogue_regs<TM, TN, MI, NI, RES_EARLY>(p, acc, rv, m0, n0, lane, wm, wn);
@@ -912,7 +949,8 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv: grid of %ld blocks", nblk); return Y3_E_INVALID; }
     a.total_tiles = (int)nblk;
     // persistent grid: as many workgroups as stay resident (LDS-limited), each walking several tiles
-    const long resident = (long)g_conv_cus * (lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3));
+    const long cus = conv_cus();
+    const long resident = cus * (lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3));
     const long grid = (g_conv_debug & 128) || nblk <= resident ? nblk : resident;
     a.delay_ticks = 0;
     a.delay_from = 0;
@@ -921,7 +959,7 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
     // a tile period late (76x76 3x3 layers: -6 %).  Delaying workgroups that have no spare round, or one of a
     // CU's two co-resident workgroups of the 128-row tiles, measured neutral to slightly slower.
     const long rem = nblk % grid;
-    if (grid == resident && resident == g_conv_cus && nblk >= 4 * resident && rem != 0 && g_conv_phase_pct > 0) {
+    if (grid == resident && resident == cus && nblk >= 4 * resident && rem != 0 && g_conv_phase_pct > 0) {
         const double tile_us = 2.0 * BM * BN * (double)a.Kpad / (BF16 ? 4.8e6 : 0.3e6);      // at ~4.8 TFLOP/s per CU
         a.delay_ticks = (unsigned)(tile_us * g_conv_phase_pct);                              // 100 ticks per us, percent
         a.delay_from = (int)rem;
@@ -988,7 +1026,7 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
         // 3x3 64->128 layers once its occupancy was pinned to two workgroups per CU)
         if (d->n_pad == 128 && d->dtype == Y3_BF16 && M >= 256L * 256) tile = 257;
         if (d->n_pad % 256 == 0) {
-            const long cus = 256;
+            const long cus = conv_cus();
             auto rounds = [&](long bm, long bnn, long per_cu) {
                 const long tiles = ((M + bm - 1) / bm) * (d->n_pad / bnn);
                 return (tiles + cus * per_cu - 1) / (cus * per_cu);
@@ -1049,6 +1087,9 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
     Y3_REQUIRE(chk.k_pad == d->k_pad && chk.n_pad == d->n_pad, Y3_E_INVALID,
                "conv: k_pad/n_pad (%d,%d) do not match the layout (%d,%d)", d->k_pad, d->n_pad, chk.k_pad, chk.n_pad);
     Y3_REQUIRE(d->stride == 1 || d->stride == 2, Y3_E_INVALID, "conv: stride %d", d->stride);
+    // the reference pads top/left for any stride > 1 (build_model.py:151-154): a 1x1 stride-2 conv would sample rows
+    // -1, 1, 3, ... -- not what this kernel's pad = 0 does, and no shipped cfg has one
+    Y3_REQUIRE(!(d->ksize == 1 && d->stride != 1), Y3_E_INVALID, "conv: 1x1 with stride %d unsupported", d->stride);
     Y3_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0, Y3_E_INVALID, "conv: empty input");
     const int pad = d->ksize == 3 ? 1 : 0;
     const int exp_h = (d->in_h + pad - d->ksize) / d->stride + 1 + (d->stride == 1 ? pad : 0);
@@ -1115,11 +1156,13 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
     a.Ho = d->out_h; a.Wo = d->out_w; a.HoWo = d->out_h * d->out_w; a.Cout8 = cout8;
     a.out_ld = d->out_ld; a.res_ld = d->res_ld;
     a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.Kpad = d->k_pad; a.M = (int)M; a.flags = d->flags;
+#ifdef Y3_EXPERIMENTS
     if (g_conv_debug & 1) a.H = 0;             // timing experiment: every A tap reads the zero page
     if (g_conv_debug & 8) a.flags |= 1 << 29;  // timing experiment: no A loads at all (garbage results)
     if (g_conv_debug & 16) a.flags |= 1 << 28; // timing experiment: no B loads at all (garbage results)
     if (g_conv_debug & 32) a.flags |= 1 << 27; // timing experiment: no epilogue (no results)
     if (g_conv_debug & 256) a.flags |= 1 << 25; // experiment: no cross-tile prefetch
+#endif
     const int bke = bf16 ? 64 : 32;
     a.n_tiles = 0;
     a.step_tap = bke / d->in_c;
@@ -1339,12 +1382,14 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     return Y3_OK;
 }
 
-// Experiment knob (not part of the stable ABI contract): force the conv tile (0 = heuristic).
+#ifdef Y3_EXPERIMENTS
+// ---- libyolo3hip_exp.so only (include/yolo3hip_experimental.h) ----
+// Experiment knob: force the conv tile (0 = heuristic).
 // Experiment knob: how many CUs one convolution launch may occupy (persistent grid size); two streams with
 // 128 each run two layers side by side.
 extern "C" int y3_set_conv_cus(int cus) {
-    Y3_REQUIRE(cus >= 8 && cus <= 256 && cus % 8 == 0, Y3_E_INVALID, "conv CUs %d (8..256, multiple of 8)", cus);
-    g_conv_cus = cus;
+    Y3_REQUIRE(cus == 0 || (cus >= 8 && cus <= 256 && cus % 8 == 0), Y3_E_INVALID, "conv CUs %d (0 = all, or 8..256 in multiples of 8)", cus);
+    g_conv_cus_cap = cus;
     return Y3_OK;
 }
 
@@ -1362,3 +1407,4 @@ extern "C" int y3_set_conv_tile(int tile) {
     g_conv_tile = tile;
     return Y3_OK;
 }
+#endif  // Y3_EXPERIMENTS

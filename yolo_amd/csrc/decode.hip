@@ -12,7 +12,11 @@
 
 namespace {
 
-bool g_decode_force_v1 = false;      // test knob: y3_decode_variant
+#ifdef Y3_EXPERIMENTS
+bool g_decode_force_v1 = false;      // test knob of libyolo3hip_exp.so: y3_decode_variant (yolo3hip_experimental.h)
+#else
+constexpr bool g_decode_force_v1 = false;
+#endif
 
 constexpr int kThreads = 256;
 constexpr int kChunk = 1024;      // boxes per block
@@ -462,11 +466,13 @@ extern "C" int y3_decode(const y3_decode_desc *d, const float *head0, const floa
     return y3_check_launch("decode");
 }
 
-// Test knob (not part of the stable contract): 1 = always the 16-lanes-per-box kernel, 0 = automatic.
+#ifdef Y3_EXPERIMENTS
+// Test knob (libyolo3hip_exp.so only): 1 = always the 16-lanes-per-box kernel, 0 = automatic.
 extern "C" int y3_decode_variant(int v) {
     g_decode_force_v1 = v == 1;
     return Y3_OK;
 }
+#endif
 
 extern "C" int y3_get_head(const float *head, int batch, int grid_h, int grid_w, int head_ld, int num_anchors,
                            int num_classes, const float *anchors_wh, float stride_x, float stride_y,

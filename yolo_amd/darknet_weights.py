@@ -48,6 +48,11 @@ def read_weights(path, layers):
         w = take(o * i * k * k).reshape(o, i, k, k)                                          # build_model.py:331
         p["kernel"] = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)))                    # build_model.py:333
         params[li] = p
+    if ptr != flat.size:
+        # the reference does not check (build_model.py:295-336); a cfg / weights mismatch must not pass silently
+        import warnings
+        warnings.warn("%s: %d of %d floats consumed by this cfg -- weights written for a different network?"
+                      % (path, ptr, flat.size), RuntimeWarning)
     return params
 
 

@@ -120,6 +120,11 @@ def infer_shapes(layers, in_h, in_w, in_c=3):
                 raise ValueError("conv size %d stride %d unsupported" % (L["size"], L["stride"]))
             if L["size"] == 3 and L["pad"] != 1:
                 raise ValueError("3x3 conv with pad=0 unsupported")
+            if L["size"] == 1 and L["stride"] > 1:
+                # the reference pads one row/column top/left for ANY stride > 1 (build_model.py:151-154), so a 1x1
+                # stride-2 conv samples rows -1, 1, 3, ... and yields h//2 + 1 outputs; no shipped cfg has one and
+                # the kernels do not implement that sampling: refuse rather than compute something else
+                raise ValueError("1x1 conv with stride %d unsupported (build_model.py:151-154 pads top/left)" % L["stride"])
             h, w = conv_out_hw(cur[0], cur[1], L["size"], L["stride"])
             cur = (h, w, L["filters"])
         elif t == "maxpool":
