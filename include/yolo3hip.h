@@ -190,6 +190,20 @@ int y3_nms_bucketed(const float *records, const int32_t *cand_idx, const int32_t
                     const int32_t *class_count, int batch, int boxes_per_image, int num_classes, int max_boxes,
                     float iou_threshold, int32_t *workspace, int32_t *kept_idx, int32_t *kept_rank,
                     int32_t *kept_count, void *stream);
+/* y3_nms_bucketed without the workspace argument, for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * class-bucketed candidate lists live in a device array built into the library instead: 8 MiB
+ * (Y3_NMS_STATIC_MAX_INTS int32) that every GPU the library runs on holds until the process ends.  The call
+ * allocates and frees nothing; it returns Y3_E_INVALID when batch * (boxes_per_image + 128) exceeds
+ * Y3_NMS_STATIC_MAX_INTS (64 images of 608x608 need 1 463 744).  The first call on a device looks the array's
+ * address up (make it outside graph capture).  All calls on one GPU share that array: calls that overlap on one
+ * GPU (two streams, two threads) race -- serialise them or use y3_nms_bucketed with workspaces of your own.
+ * Same results as y3_nms_bucketed / y3_nms, bit for bit. */
+#define Y3_NMS_STATIC_MAX_INTS (2 * 1024 * 1024)
+int y3_nms_bucketed_static(const float *records, const int32_t *cand_idx, const int32_t *cand_count,
+                           const int32_t *class_count, int batch, int boxes_per_image, int num_classes, int max_boxes,
+                           float iou_threshold, int32_t *kept_idx, int32_t *kept_rank, int32_t *kept_count,
+                           void *stream);
 /* dynamic LDS the NMS kernel takes for this pool size (host-only helper). */
 int y3_nms_lds_bytes(int boxes_per_image);
 

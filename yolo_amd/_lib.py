@@ -51,6 +51,7 @@ SIGNATURES = {
     "y3_expand_scores": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "y3_nms": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "y3_nms_bucketed": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_nms_bucketed_static": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "y3_nms_workspace_ints": (c_i64, [c_int, c_int]),
     "y3_nms_lds_bytes": (c_int, [c_int]),
     "y3_pack_outputs": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),

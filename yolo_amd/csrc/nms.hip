@@ -546,6 +546,55 @@ extern "C" int y3_nms_bucketed(const float *records, const int32_t *cand_idx, co
                       workspace, kept_idx, kept_rank, kept_count, (hipStream_t)stream);
 }
 
+// ---- the one entry point that allocates nothing and takes no workspace -----------------------------------------
+// y3_nms_bucketed's class-bucketed candidate lists (its `workspace` argument) live in a file-scope device array
+// instead.  Each GPU the library runs on holds its own copy of the array until the process ends; the array's name
+// is only a host-side handle, so the device address is looked up once per device (hipGetSymbolAddress, with that
+// device current) and that pointer is what the kernels, like y3_nms_bucketed's, receive as an argument.
+// Nothing in the array has to start at zero: nms_bucket_kernel writes every header word and every list entry the
+// later kernels read, whatever an earlier call left behind.  Calls that overlap on one GPU share the array and race.
+namespace {
+constexpr long kStaticWsInts = Y3_NMS_STATIC_MAX_INTS;       // 8 MiB per GPU: batch * (boxes_per_image + 128) ints
+static __device__ __align__(256) int scratch[kStaticWsInts];
+int *g_scratch_ptr[64] = {nullptr};                          // per device; written once, under g_scratch_lock
+int g_scratch_lock = 0;
+}  // namespace
+
+extern "C" int y3_nms_bucketed_static(const float *records, const int32_t *cand_idx, const int32_t *cand_count,
+                                      const int32_t *class_count, int batch, int boxes_per_image, int num_classes,
+                                      int max_boxes, float iou_threshold, int32_t *kept_idx, int32_t *kept_rank,
+                                      int32_t *kept_count, void *stream) {
+    Y3_REQUIRE(batch > 0 && boxes_per_image > 0, Y3_E_INVALID, "nms_bucketed_static: bad shape");
+    const long need = (long)batch * (boxes_per_image + kWsHeader);
+    Y3_REQUIRE(need <= kStaticWsInts, Y3_E_INVALID,
+               "nms_bucketed_static: batch %d x %d boxes needs %ld ints of scratch, the built-in array holds %ld "
+               "(use y3_nms_bucketed with a workspace of your own)", batch, boxes_per_image, need, kStaticWsInts);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        y3_set_error("nms_bucketed_static: device %d (0..63 supported)", dev);
+        return Y3_E_LAUNCH;
+    }
+    int *ws = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (ws == nullptr) {                                     // first call on this device: resolve ITS copy of the array
+        while (__atomic_exchange_n(&g_scratch_lock, 1, __ATOMIC_ACQUIRE)) {}
+        ws = g_scratch_ptr[dev];
+        if (ws == nullptr) {
+            void *p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || p == nullptr) {
+                __atomic_store_n(&g_scratch_lock, 0, __ATOMIC_RELEASE);
+                y3_set_error("nms_bucketed_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+                return Y3_E_LAUNCH;
+            }
+            ws = (int *)p;
+            __atomic_store_n(&g_scratch_ptr[dev], ws, __ATOMIC_RELEASE);
+        }
+        __atomic_store_n(&g_scratch_lock, 0, __ATOMIC_RELEASE);
+    }
+    return launch_nms(records, cand_idx, cand_count, class_count, batch, boxes_per_image, num_classes, max_boxes, iou_threshold,
+                      ws, kept_idx, kept_rank, kept_count, (hipStream_t)stream);
+}
+
 extern "C" int y3_pack_outputs(const float *records, const int32_t *kept_idx, const int32_t *kept_count, int batch,
                                int boxes_per_image, int num_classes, int max_boxes, float *out_boxes,
                                float *out_scores, int32_t *out_classes, int32_t *out_count, void *stream) {
