@@ -160,7 +160,7 @@ def main():
     if warm_trace:
         acc = {}
         for op, e0, e1 in warm_trace:
-            if op["kind"] in ("conv", "stem"):
+            if op["kind"] in ("conv", "stem", "resblock"):
                 acc[op["kernel"]] = acc.get(op["kernel"], 0.0) + e0.elapsed_time(e1)
         dom_kernel = max(acc, key=acc.get)
     only_dom = (lambda op: op.get("kernel") == dom_kernel) if dom_kernel else None
@@ -218,7 +218,7 @@ def main():
             for tr in traces:
                 for op, e0, e1 in tr:
                     ms = e0.elapsed_time(e1)
-                    if op["kind"] in ("conv", "stem"):
+                    if op["kind"] in ("conv", "stem", "resblock"):
                         conv_ms += ms
                         k = per_kernel.setdefault(op["kernel"], [0.0, 0.0, 0])
                         k[0] += ms; k[1] += conv_flops(op, nb); k[2] += 1
@@ -243,16 +243,16 @@ def main():
                         out["roofline"]["traffic_source"] = tj["source"]
             except (OSError, ValueError, KeyError):
                 pass
-            w_conv = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] in ("conv", "stem"))
+            w_conv = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] in ("conv", "stem", "resblock"))
             w_post = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] == "post")
-            w_other = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] not in ("conv", "stem", "post"))
+            w_other = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] not in ("conv", "stem", "resblock", "post"))
             out["stage_ms_per_step"] = {"conv_all": round(w_conv, 3), "other_layers": round(w_other, 3),
                                         "decode_nms_pack": round(w_post, 3),
                                         "note": "from one fully traced warm-up step, whose ~150 event pairs add ~3 us "
                                                 "of stream time each: the stages sum to more than ms_per_step"}
             wk = {}
             for op, e0, e1 in warm_trace:
-                if op["kind"] in ("conv", "stem"):
+                if op["kind"] in ("conv", "stem", "resblock"):
                     v = wk.setdefault(op["kernel"], [0.0, 0.0, 0])
                     v[0] += e0.elapsed_time(e1); v[1] += conv_flops(op, nb); v[2] += 1
             out["kernels"] = {k + ">": {"ms_per_step": round(v[0], 3), "launches_per_step": v[2],

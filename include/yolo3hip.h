@@ -110,6 +110,27 @@ int y3_conv_stem(const y3_stem_desc *desc, const float *image, const float *w0, 
                  const void *w1, const float *b1, const void *w2, const float *b2,
                  void *out1, void *out2, void *stream);
 
+/* Fused residual block, bf16: out = x + act2(conv3x3(act1(conv1x1(x; w1) + b1); w2) + b2) in one launch -- the
+ * [convolutional 1x1 c -> c/2], [convolutional 3x3 c/2 -> c] and [shortcut from=-3] sections that make up a Darknet-53
+ * residual block (build_model.py:113-179 twice, then :218-227).  The c/2-channel tensor between the two convolutions
+ * never leaves LDS and x is fetched once.  w1/b1 and w2/b2 are the two layers' packed weights exactly as
+ * y3_conv_weight_layout / y3_conv2d_fused take them; the result is bit-identical to y3_conv2d_fused(1x1) followed by
+ * y3_conv2d_fused(3x3, Y3_CONV_RESIDUAL) on the same operands.  Supported: dtype Y3_BF16, c = 256 or 128, w a multiple
+ * of 19 (the 76 / 152 feature maps of a 608 input), tensors below 4 GiB.  flags: 1 = leaky-ReLU after the 1x1,
+ * 2 = after the 3x3, Y3_CONV_REVERSE = scheduling hint.  y3_resblock_tiles (host only) says whether a shape is
+ * supported (Y3_OK) and how many workgroup tiles it has, so that a planner can decide when fusing pays. */
+typedef struct y3_resblock_desc {
+    int32_t dtype;        /* Y3_BF16                                                                  */
+    int32_t batch, h, w;  /* NHWC activations, same size in and out                                    */
+    int32_t c;            /* channels of x and out; the 1x1 produces c/2                               */
+    int32_t x_ld, out_ld; /* elements between consecutive pixels                                       */
+    int32_t k1_pad, n1_pad, k2_pad, n2_pad;   /* packed layouts of the two weight matrices             */
+    int32_t flags;
+} y3_resblock_desc;
+int y3_resblock_tiles(const y3_resblock_desc *desc, int64_t *tiles);
+int y3_resblock_fused(const y3_resblock_desc *desc, const void *x, const void *w1, const float *b1,
+                      const void *w2, const float *b2, void *out, const void *zeros, void *stream);
+
 /* Name (prefix) of the kernel a descriptor will run on, as rocprofv3 reports it. Host-only. */
 int y3_conv_kernel_name(const y3_conv_desc *desc, char *buf, int len);
 

@@ -80,6 +80,22 @@ class Sim(object):
                             self.write(op["y"], (b * 2 * oh + 2 * ho + dy) * 2 * ow + 2 * wo + dx, y)
                 else:
                     self.write(op["y"], np.arange(B * oh * ow), y)
+            elif k == "resblock":                     # 1x1 -> 3x3 -> + x, the 1x1's output staying inside the op
+                h, w = op["hw"]; c = op["c"]
+                i1, i3, _ = op["layers"]
+                x = self.read(op["x"], B * h * w)
+                w1, b1 = self.w[i1]
+                w3, b3 = self.w[i3]
+                y = x @ w1.T + b1
+                if op["leaky"][0]:
+                    y = np.where(y > 0, y, np.float32(0.1) * y)
+                yp = np.zeros((B, h + 2, w + 2, c // 2), dtype=np.float32)
+                yp[:, 1:1 + h, 1:1 + w] = y.reshape(B, h, w, c // 2)
+                a = np.concatenate([yp[:, kh:kh + h, kw:kw + w, :] for kh in range(3) for kw in range(3)], axis=-1)
+                z = a.reshape(B * h * w, 9 * (c // 2)) @ w3.T + b3
+                if op["leaky"][1]:
+                    z = np.where(z > 0, z, np.float32(0.1) * z)
+                self.write(op["y"], np.arange(B * h * w), (x + z).astype(np.float32))
             elif k == "padin":
                 x = self.read(op["x"], op["pixels"])
                 y = np.zeros((op["pixels"], op["y"]["c"]), dtype=np.float32)

@@ -31,13 +31,14 @@ def _view(cp, ref, heads, B, hw, dtype):
     return torch.as_strided(base, (n, ref["c"]), (ref["ld"], 1), base.storage_offset() + ref["off"])
 
 
-@pytest.mark.parametrize("cfg_name,size,batch", [("yolov3", 160, 2), ("yolov3", 608, 1), ("yolov3-tiny", 416, 2), ("yolov3-spp", 160, 1)])
-def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch):
+@pytest.mark.parametrize("cfg_name,size,batch,resblock", [("yolov3", 160, 2, None), ("yolov3", 608, 1, None), ("yolov3", 608, 1, True),
+                                                          ("yolov3-tiny", 416, 2, None), ("yolov3-spp", 160, 1, None)])
+def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch, resblock):
     cfg = {"yolov3": config.yolov3_cfg_path, "yolov3-tiny": config.yolov3_tiny_cfg_path, "yolov3-spp": config.yolov3_spp_cfg_path}[cfg_name]
     layers, oi = od.parse_layers(cfg, 80)
     params = dw.random_params(layers, seed=31)
     x = np.random.default_rng(31).random((batch, size, size, 3), dtype=np.float32)
-    net = build_model.Network(cfg, 80, dtype="bf16")
+    net = build_model.Network(cfg, 80, dtype="bf16", resblock=resblock)     # True: the ten residual blocks as fused launches
     net.set_params(params)
     cp = net.plan_for(batch, size, size)
     has_stem = cp.plan.ops[0]["kind"] == "stem"          # otherwise the 3-channel first layer runs in fp32 (direct kernel)
@@ -56,7 +57,7 @@ def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch):
             outs.append(("y", op["layers"][1]))
             if op.get("y2") is not None:
                 outs.append(("y2", op["layers"][2]))
-        elif op["kind"] == "conv":
+        elif op["kind"] in ("conv", "resblock"):
             outs.append(("y", op["writes_layer"]))
         elif op["kind"] in ("maxpool", "upsample", "add"):
             outs.append(("y", op["layer"]))
@@ -76,9 +77,10 @@ def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch):
                 # summation order moves a value that is small against its own terms.  The stem's conv B / C run
                 # on conv A's / conv B's output inside the launch, which cannot be forced: one flipped input there
                 # (one bf16 ulp of a value of a few units) times a weight moves an output by up to ~1 ulp of the
-                # tensor's largest value, hence the wider absolute term for the stem's two tensors.
+                # tensor's largest value, hence the wider absolute term for the stem's two tensors -- and for a fused
+                # residual block, whose 3x3 runs on the 1x1's output inside the launch.
                 big = max(1.0, float(np.abs(want).max()))
-                floor = 2.0 ** -7 * big if op["kind"] == "stem" else 4e-6 * big
+                floor = 2.0 ** -7 * big if op["kind"] in ("stem", "resblock") else 4e-6 * big
                 assert np.all(err <= np.abs(want) * 2.0 ** -7 + floor), "layer %d: more than one bf16 ulp" % li
                 flipped += int((err > 0).sum())
                 total += err.size
@@ -86,7 +88,9 @@ def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch):
             worst = max(worst, float((err / np.maximum(np.abs(want), 1e-3)).max()))
             checked += 1
     n_conv = sum(1 for L in layers if L["type"] == "conv")
-    assert checked >= n_conv - 1                     # every convolution's tensor (the stem writes two of three)
+    n_rb = sum(1 for op in cp.plan.ops if op["kind"] == "resblock")
+    assert (n_rb == 10) == bool(resblock)
+    assert checked >= n_conv - 1 - n_rb              # every convolution's tensor (the stem writes two of three, a fused block one of two)
     print("%s %d b%d: %d tensors checked, %d of %d bf16 elements off by one ulp (%.2e), worst relative %.2e"
           % (cfg_name, size, batch, checked, flipped, total, flipped / max(total, 1), worst))
     assert flipped <= 2e-3 * total

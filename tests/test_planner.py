@@ -127,3 +127,31 @@ def test_direct_first_layer_plan_still_available():
 def test_padded_input_plan_matches_oracle():
     plan = _check(config.yolov3_tiny_cfg_path, 416, 1, True, pad_input=True)
     assert plan.ops[0]["kind"] == "padin"
+
+
+def test_residual_blocks_fuse_into_one_op():
+    """1x1 -> 3x3 -> shortcut with 256 / 128 channels on a map whose width is a multiple of 19 becomes one `resblock`
+    op (csrc/conv_resblock.hip): the 1x1's output gets no buffer.  Interpreted in numpy, the fused plan gives the
+    oracle's heads; automatic mode fuses only the widths that measured faster (RESBLOCK_AUTO_CHANNELS), only launches of
+    >= RESBLOCK_MIN_TILES tiles, and only in bf16 plans."""
+    cfg = config.yolov3_cfg_path
+    layers, oi = planner.parse_cfg(cfg, 80)
+    ol, ooi = od.parse_layers(cfg, 80)
+    params = dw.random_params(layers, seed=11)
+    x = np.random.default_rng(1).random((1, 608, 608, 3), dtype=np.float32)           # 608 = 32 * 19: the only input size with such maps
+    ref = od.forward(ol, ooi, params, x)
+    plan = planner.build_plan(layers, oi, 1, 608, 608, "fp32", resblock=True)
+    rbs = [op for op in plan.ops if op["kind"] == "resblock"]
+    assert [(op["c"], op["hw"]) for op in rbs] == [(128, (152, 152))] * 2 + [(256, (76, 76))] * 8
+    assert len(plan.ops) == 75 - 10 and all(op["writes_layer"] == op["layers"][2] for op in rbs)
+    for a, b in zip(plan_sim.Sim(plan, layers, params, x).run(), ref):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4)
+    big = planner.build_plan(layers, oi, 64, 608, 608, "bf16")
+    assert [(op["c"], op["tiles"]) for op in big.ops if op["kind"] == "resblock"] == [(128, 6144)] * 2 and len(big.ops) == 71
+    every = planner.build_plan(layers, oi, 64, 608, 608, "bf16", resblock=True)
+    assert [op["tiles"] for op in every.ops if op["kind"] == "resblock"] == [6144] * 2 + [1536] * 8 and len(every.ops) == 63
+    assert not any(op["kind"] == "resblock" for op in planner.build_plan(layers, oi, 1, 608, 608, "bf16").ops)
+    assert not any(op["kind"] == "resblock" for op in planner.build_plan(layers, oi, 64, 608, 608, "fp32").ops)
+    assert not any(op["kind"] == "resblock" for op in planner.build_plan(layers, oi, 64, 416, 416, "bf16").ops)
+    small = planner.build_plan(layers, oi, 64, 608, 608, "bf16", resblock=False)
+    assert big.arena_bytes <= small.arena_bytes

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-stem", action="store_true")
     ap.add_argument("--splitk", action="store_true")
+    ap.add_argument("--no-resblock", action="store_true", help="residual blocks as two launches (1x1, 3x3 + shortcut)")
     ap.add_argument("--phase", type=int, default=-1, help="de-phasing offset in percent of a tile period (0 = off)")
     a = ap.parse_args()
     cfg = config.yolov3_tiny_cfg_path if a.model == "yolov3-tiny" else config.yolov3_cfg_path
@@ -33,7 +34,8 @@ def main():
         _lib.check(_lib.load().y3_set_conv_tile(a.tile))
         if a.phase >= 0:
             _lib.check(_lib.load().y3_set_conv_phase(a.phase))
-    net = build_model.Network(cfg, 80, dtype=a.dtype, stem=not a.no_stem, splitk=a.splitk)
+    net = build_model.Network(cfg, 80, dtype=a.dtype, stem=not a.no_stem, splitk=a.splitk,
+                              resblock=False if a.no_resblock else None)
     net.set_params(dw.random_params(net.layers, seed=0))
     x = torch.rand((a.batch, a.size, a.size, 3), device="cuda")
     for _ in range(2):
@@ -59,6 +61,8 @@ def main():
             oh = op["out_hw"][0]
             shape = "%dx%d s%d %d->%d @%d%s%s" % (op["ksize"], op["ksize"], op["stride"], op["in_c"], op["out_c"], oh,
                                                   "+r" if op["res"] is not None else "", "+u" if op["ups"] else "")
+        elif op["kind"] == "resblock":
+            shape = "block 1x1+3x3+r %d->%d->%d @%d" % (op["c"], op["c"] // 2, op["c"], op["hw"][0])
         elif op["kind"] == "stem":
             shape = "stem 3->" + "->".join(str(c["out_c"]) for c in op["convs"]) + " @%d" % op["out_hw"][0]
         else:

@@ -24,6 +24,11 @@ class StemDesc(ctypes.Structure):
         "batch", "in_h", "in_w", "c0", "c1", "c2", "n0_pad", "k1_pad", "k2_pad", "out1_ld", "out2_ld", "flags")]
 
 
+class ResblockDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "dtype", "batch", "h", "w", "c", "x_ld", "out_ld", "k1_pad", "n1_pad", "k2_pad", "n2_pad", "flags")]
+
+
 class DecodeDesc(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int32), ("num_scales", ctypes.c_int32), ("num_classes", ctypes.c_int32),
                 ("num_anchors", ctypes.c_int32), ("grid_h", ctypes.c_int32 * 3), ("grid_w", ctypes.c_int32 * 3),
@@ -39,6 +44,8 @@ SIGNATURES = {
     "y3_conv_splitk_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]),
     "y3_conv2d_splitk": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, c_vp]),
     "y3_conv_stem": (c_int, [ctypes.POINTER(StemDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_resblock_tiles": (c_int, [ctypes.POINTER(ResblockDesc), ctypes.POINTER(ctypes.c_int64)]),
+    "y3_resblock_fused": (c_int, [ctypes.POINTER(ResblockDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "y3_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_int]),
     "y3_maxpool2d": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "y3_upsample2x": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),

@@ -169,6 +169,28 @@ class _CompiledPlan(object):
             def launch(env, _keep=(d, w, bias)):
                 return fn(dref, x(env), wp, bp, r(env), y(env), zp, env["stream"])
             return launch
+        if kind == "resblock":
+            i1, i3, _ = op["layers"]
+            w1, b1, fam1, k1_pad, n1_pad = net._packed[i1]
+            w2, b2, fam2, k2_pad, n2_pad = net._packed[i3]
+            assert fam1 == 0 and fam2 == 0, "resblock: unexpected weight layouts"
+            d = _lib.ResblockDesc()
+            d.dtype, d.batch = code, B
+            d.h, d.w = op["hw"]
+            d.c, d.x_ld, d.out_ld = op["c"], op["x"]["ld"], op["y"]["ld"]
+            d.k1_pad, d.n1_pad, d.k2_pad, d.n2_pad = k1_pad, n1_pad, k2_pad, n2_pad
+            d.flags = (1 if op["leaky"][0] else 0) | (2 if op["leaky"][1] else 0) | (_lib.CONV_REVERSE if op.get("reverse") else 0)
+            dref = ctypes.byref(d)
+            tiles = ctypes.c_int64(0)
+            _lib.check(lib.y3_resblock_tiles(dref, ctypes.byref(tiles)))
+            op["kernel"] = "resblock_kernel<%d, %d, %d" % ((128, 2, 4) if op["c"] == 256 else (64, 4, 2))
+            x, y = resolver(op["x"]), resolver(op["y"])
+            ptrs = (w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), net._zeros.data_ptr())
+            fn = lib.y3_resblock_fused
+
+            def launch(env, _keep=(d, w1, b1, w2, b2)):
+                return fn(dref, x(env), ptrs[0], ptrs[1], ptrs[2], ptrs[3], y(env), ptrs[4], env["stream"])
+            return launch
         if kind == "stem":
             i0, i1, i2 = op["layers"]
             w0, b0, fam0, _, n0_pad = net._packed[i0]
@@ -226,7 +248,7 @@ class Network(object):
     """The compiled detector: cfg layers + packed device weights + cached launch plans."""
 
     def __init__(self, config_path, num_classes, dtype=None, device=None, fuse=True, pad_input=False, stem=True,
-                 snake=None, splitk=False):
+                 snake=None, splitk=False, resblock=None):
         self.config_path = config_path
         self.num_classes = num_classes
         self.dtype = dtype or config.compute_dtype
@@ -242,6 +264,11 @@ class Network(object):
         # split-K for launches with few output tiles (small batches: latency mode).  Off by default: split sums are
         # added in another order, so results are no longer bit-identical across batch sizes / chunking.
         self.splitk = bool(splitk)
+        # residual blocks (1x1 -> 3x3 -> shortcut) as one launch: None = where the planner finds it pays (bf16, large
+        # launches), False = never; YOLO_AMD_RESBLOCK=0 for A/B runs.  Same bits either way.
+        if resblock is None and os.environ.get("YOLO_AMD_RESBLOCK") == "0":
+            resblock = False
+        self.resblock = resblock
         self.layers, self.out_index = planner.parse_cfg(config_path, num_classes, config.num_anchors_per_scale)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.params = None
@@ -283,7 +310,8 @@ class Network(object):
             if self._packed is None:
                 raise RuntimeError("weights are not loaded: call load_weights(net, path) first")
             plan = planner.build_plan(self.layers, self.out_index, batch, height, width, self.dtype, fuse=self.fuse,
-                                      pad_input=self.pad_input, stem=self.stem, snake=self.snake)
+                                      pad_input=self.pad_input, stem=self.stem, snake=self.snake,
+                                      resblock=(None if self.dtype == "bf16" else False) if self.resblock is None else self.resblock)
             cp = _CompiledPlan(self, plan)
             self._plans[key] = cp
         return cp

@@ -19,5 +19,21 @@ int y3_check_launch(const char *what) {
     return Y3_OK;
 }
 
+int y3_device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int slot = dev >= 0 && dev < 64 ? dev : 0;
+    int v = __atomic_load_n(&cached[slot], __ATOMIC_RELAXED);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
+            (void)hipGetLastError();
+            v = 256;
+        }
+        __atomic_store_n(&cached[slot], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
+
 extern "C" int y3_version(void) { return Y3_VERSION; }
 extern "C" const char *y3_last_error(void) { return g_err; }

@@ -73,3 +73,41 @@ __device__ __forceinline__ unsigned dpp_u(unsigned v) {
 }
 
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Compute units of the current device (MI355X: 256; fewer in a partitioned mode), queried once per device (api.hip).
+// Sizes the persistent grids, the de-phasing condition and the wave-quantisation model of the convolution launchers.
+int y3_device_cus();
+
+// ---- shared by the convolution kernels (conv_igemm.hip, conv_resblock.hip) ------------------------------------
+struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
+
+__device__ __forceinline__ int fast_div(int n, FastDiv d) {
+    return (int)((__umulhi((unsigned)n, d.magic) + (unsigned)n) >> d.shift);
+}
+
+static inline FastDiv make_fastdiv(int d) {
+    unsigned shift = 0;
+    while ((1ull << shift) < (unsigned long long)d) ++shift;
+    FastDiv f;
+    f.magic = (unsigned)((((1ull << 32) * ((1ull << shift) - (unsigned long long)d)) / (unsigned long long)d) + 1);
+    f.shift = shift;
+    return f;
+}
+
+__device__ __forceinline__ int xcd_remap(int orig, int nblk, bool reverse = false) {
+    // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
+    // range of logical tiles so that the n-tiles of one m-tile (which share the
+    // gathered input) and neighbouring m-tiles (which share halo rows) meet in one L2.
+    // reverse: the XCD walks its range from the end (Y3_CONV_REVERSE: consecutive layers alternate, so a layer
+    // starts on what the previous one wrote last -- still in L2 / Infinity Cache).
+    const int q = nblk >> 3, r = nblk & 7, x = orig & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const int len = q + (x < r ? 1 : 0), i = orig >> 3;
+    return start + (reverse ? len - 1 - i : i);
+}
+
+// One LDS-DMA instruction: 16 bytes per lane from a per-lane global address to (wave-uniform LDS base + lane * 16).
+__device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}

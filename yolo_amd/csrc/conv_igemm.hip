@@ -51,33 +51,9 @@ int g_conv_phase_pct = 50;          // start offset of the de-phased workgroups,
 constexpr int g_conv_tile = 0, g_conv_debug = 0, g_conv_cus_cap = 0, g_conv_phase_pct = 50;
 #endif
 
-// Compute units of the current device (MI355X: 256; fewer in a partitioned mode), queried once per device.
-// Sizes the persistent grids, the de-phasing condition and the wave-quantisation model of conv_variant.
-int device_cus() {
-    static int cached[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const int slot = dev >= 0 && dev < 64 ? dev : 0;
-    int v = __atomic_load_n(&cached[slot], __ATOMIC_RELAXED);
-    if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
-            (void)hipGetLastError();
-            v = 256;
-        }
-        __atomic_store_n(&cached[slot], v, __ATOMIC_RELAXED);
-    }
-    return v;
-}
-
 int conv_cus() {
-    const int cus = device_cus();
+    const int cus = y3_device_cus();
     return g_conv_cus_cap > 0 && g_conv_cus_cap < cus ? g_conv_cus_cap : cus;
-}
-
-struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
-
-__device__ __forceinline__ int fast_div(int n, FastDiv d) {
-    return (int)((__umulhi((unsigned)n, d.magic) + (unsigned)n) >> d.shift);
 }
 
 struct ConvArgs {
@@ -115,23 +91,6 @@ __device__ __forceinline__ void row_setup(const ConvArgs &p, int gm, int es, lon
         for (int k = 0; k < 3; ++k) m |= ((unsigned)(hi0 + k) < (unsigned)p.H ? vw : 0u) << (3 * k);
         mask = m;
     }
-}
-
-__device__ __forceinline__ int xcd_remap(int orig, int nblk, bool reverse = false) {
-    // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
-    // range of logical tiles so that the n-tiles of one m-tile (which share the
-    // gathered input) and neighbouring m-tiles (which share halo rows) meet in one L2.
-    // reverse: the XCD walks its range from the end (Y3_CONV_REVERSE: consecutive layers alternate, so a layer
-    // starts on what the previous one wrote last -- still in L2 / Infinity Cache).
-    const int q = nblk >> 3, r = nblk & 7, x = orig & 7;
-    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    const int len = q + (x < r ? 1 : 0), i = orig >> 3;
-    return start + (reverse ? len - 1 - i : i);
-}
-
-__device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
 constexpr int CONV_NO_BIAS = 1 << 24;    // internal flag: split-K partial sums carry no bias
@@ -1037,15 +996,6 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
     }
     if ((tile >= 192 || tile == 129) && tile != 257 && tile != 258 && d->n_pad % 256 != 0) tile = 128;
     return tile;
-}
-
-inline FastDiv make_fastdiv(int d) {
-    unsigned shift = 0;
-    while ((1ull << shift) < (unsigned long long)d) ++shift;
-    FastDiv f;
-    f.magic = (unsigned)((((1ull << 32) * ((1ull << shift) - (unsigned long long)d)) / (unsigned long long)d) + 1);
-    f.shift = shift;
-    return f;
 }
 
 inline int bn_for(int out_c) { return out_c > 64 ? 128 : (out_c > 32 ? 64 : 32); }

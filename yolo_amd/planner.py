@@ -184,8 +184,59 @@ def find_stem(layers, inputs, uses, head_of, in_c=3):
     return (i0, i1, i2)
 
 
+RESBLOCK_TILE_W, RESBLOCK_TILE_H = 19, 13      # csrc/conv_resblock.hip: RB_TW, RB_TH
+RESBLOCK_MIN_TILES = 1024                      # fuse only where the launch fills the chip several times over
+# Block widths the automatic mode fuses.  Measured at batch 64 / 608: C = 128 @152 0.42 ms fused against
+# 0.47 ms in two launches; C = 256 @76 0.317 ms against 0.29 ms (the tile boundary of the fused kernel is bound by the
+# CU's ~15 B/clk memory ingest, which the 1x1 launch, HBM-bound chip-wide, does not pay), so 256 stays un-fused.
+RESBLOCK_AUTO_CHANNELS = (128,)
+
+
+def resblock_tiles(batch, h, w):
+    """Workgroup tiles of y3_resblock_fused on a [batch, h, w, c] tensor, or 0 when the shape is not supported."""
+    if w % RESBLOCK_TILE_W:
+        return 0
+    return batch * (-(-h // RESBLOCK_TILE_H)) * (w // RESBLOCK_TILE_W)
+
+
+def find_resblocks(layers, inputs, uses, head_of, shapes, batch, dtype, mode, channels=None):
+    """Darknet residual blocks that run as ONE launch (csrc/conv_resblock.hip): [convolutional 1x1 C -> C/2],
+    [convolutional 3x3 C/2 -> C], [shortcut from=-3] with C = 256 or 128 on a feature map whose width is a multiple of
+    19, bf16.  mode: None = automatic (bf16 plans, C in RESBLOCK_AUTO_CHANNELS, launches of at least
+    RESBLOCK_MIN_TILES tiles: at small batch the un-fused 128-pixel tiles fill the chip better, and both forms give the
+    same bits), True = wherever the pattern fits (tests), False = never.  channels overrides the widths considered.
+    Returns {index of the 3x3: (i1, i3, i_shortcut)}."""
+    found = {}
+    if channels is None:
+        channels = RESBLOCK_AUTO_CHANNELS if mode is None else (256, 128)
+    if mode is False or (mode is None and dtype != "bf16"):
+        return found
+    for i3, L3 in enumerate(layers):
+        if i3 < 1 or i3 + 1 >= len(layers) or L3["type"] != "conv":
+            continue
+        i1, isc = inputs[i3][0], i3 + 1
+        if i1 < 0 or layers[i1]["type"] != "conv" or layers[isc]["type"] != "shortcut":
+            continue
+        L1, S = layers[i1], layers[isc]
+        src = inputs[i1][0]
+        if src < 0 or inputs[isc] != [src, i3] or S["src"] != src:
+            continue
+        c = shapes[src][2]
+        if c not in channels or (L1["size"], L1["stride"], L1["filters"]) != (1, 1, c // 2):
+            continue
+        if (L3["size"], L3["stride"], L3["filters"], L3["pad"]) != (3, 1, c, 1):
+            continue
+        if uses[i1] != 1 or uses[i3] != 1 or i1 in head_of or i3 in head_of:
+            continue
+        tiles = resblock_tiles(batch, shapes[src][0], shapes[src][1])
+        if tiles == 0 or (mode is None and tiles < RESBLOCK_MIN_TILES):
+            continue
+        found[i3] = (i1, i3, isc)
+    return found
+
+
 def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True, pad_input=False, stem=True,
-               snake=True):
+               snake=True, resblock=None):
     assert dtype in ("bf16", "fp32")
     es = 2 if dtype == "bf16" else 4
     epc = 16 // es
@@ -255,6 +306,12 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
             fused_into[i] = p
             absorbed[p] = i
 
+    rb_env = os.environ.get("YOLO_AMD_RESBLOCK_C")                                        # A/B runs: "256,128", "128"
+    rb_channels = tuple(int(v) for v in rb_env.split(",") if v) if rb_env else None
+    resblocks = find_resblocks(layers, inputs, uses, head_of, shapes, batch, dtype, resblock, rb_channels) if fuse else {}
+    resblocks = {i3: v for i3, v in resblocks.items() if fused_into.get(v[2]) == i3}     # the shortcut rides the 3x3
+    rb_internal = {v[0] for v in resblocks.values()}      # 1x1 outputs that never leave LDS: no buffer, no launch
+
     # ---- storage: aliases, concat slices, own buffers ---------------------------------------
     bufs = []            # dict(elems, es, kind)
     tens = [None] * n    # dict(buf, off, ld, c)  (off/ld in elements)
@@ -287,7 +344,7 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
 
     for i, L in enumerate(layers):
         t = L["type"]
-        if t == "yolo" or i in absorbed or (stem_layers is not None and i == stem_layers[0]):
+        if t == "yolo" or i in absorbed or i in rb_internal or (stem_layers is not None and i == stem_layers[0]):
             continue
         c = shapes[i][2]
         if t == "route":
@@ -335,6 +392,16 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
                                 leaky=tuple(layers[j]["activation"] == "leaky" for j in stem_layers if j is not None),
                                 convs=[dict(out_hw=shapes[j][:2], out_c=shapes[j][2], ksize=layers[j]["size"], in_c=layers[j]["cin"])
                                        for j in stem_layers if j is not None]))
+        elif t == "conv" and i in rb_internal:
+            plan.conv_layers.append(i)                 # computed inside the block's launch (emitted at its 3x3)
+        elif t == "conv" and i in resblocks:
+            plan.conv_layers.append(i)
+            i1, i3, isc = resblocks[i]
+            src = inputs[i1][0]
+            h, w, c = shapes[src]
+            ops.append(dict(kind="resblock", layer=i1, layers=(i1, i3, isc), x=tens[src], y=tens[isc], hw=(h, w), c=c,
+                            leaky=(layers[i1]["activation"] == "leaky", layers[i3]["activation"] == "leaky"),
+                            writes_layer=isc, tiles=resblock_tiles(batch, h, w)))
         elif t == "conv":
             plan.conv_layers.append(i)
             src = inputs[i][0]
@@ -435,8 +502,8 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
     # on the part of its input that the previous one wrote last (still in L2 / Infinity Cache) -- same results.
     k = 0
     for op in ops:
-        if op["kind"] in ("conv", "stem"):
-            op["reverse"] = bool(snake and (k & 1) and op["kind"] == "conv")
+        if op["kind"] in ("conv", "stem", "resblock"):
+            op["reverse"] = bool(snake and (k & 1) and op["kind"] != "stem")
             k += 1
     return plan
 
@@ -448,6 +515,10 @@ def op_flops(op, batch):
         return 2.0 * batch * oh * ow * op["out_c"] * op["ksize"] ** 2 * op["in_c"]
     if op["kind"] == "stem":
         return sum(2.0 * batch * c["out_hw"][0] * c["out_hw"][1] * c["out_c"] * c["ksize"] ** 2 * c["in_c"] for c in op["convs"])
+    if op["kind"] == "resblock":                 # the two convolutions' algorithmic FLOPs (halo recomputation not counted)
+        h, w = op["hw"]
+        c = op["c"]
+        return 2.0 * batch * h * w * (c * (c // 2) + 9 * (c // 2) * c)
     return 0.0
 
 
@@ -461,6 +532,10 @@ def op_bytes(op, batch, es):
         if op["res"] is not None:
             byt += batch * oh * ow * op["out_c"] * es
         return float(byt)
+    if op["kind"] == "resblock":                 # x once, out once, both weight matrices
+        h, w = op["hw"]
+        c = op["c"]
+        return float(2 * batch * h * w * c * es + (c * (c // 2) + 9 * (c // 2) * c) * es)
     if op["kind"] == "stem":
         ih, iw = op["in_hw"]; oh, ow = op["out_hw"]
         byt = batch * ih * iw * 3 * 4
