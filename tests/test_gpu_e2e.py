@@ -314,6 +314,43 @@ def test_run_inference_image_dir_contract(tmp_path, graph):
     assert found > 0
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_run_inference_batched_writes_the_same_files(tmp_path, dtype):
+    """`--batch N` runs the directory in chunks of N images per step (last chunk shorter; with --graph it replays the
+    full-batch graph): every label file and every annotated image is byte-identical to the one-image-per-step run
+    (--no_splitk: split-K adds partial sums in another order), because a batch is B independent batch-1 runs and the
+    batched plan gives an image the same bits at every batch size."""
+    import argparse
+    import filecmp
+    from PIL import Image
+    from yolo_amd import planner
+    rng = np.random.default_rng(8)
+    img_dir = tmp_path / "imgs"
+    img_dir.mkdir()
+    shapes = [(120, 160), (200, 150), (96, 96), (64, 300), (333, 222)]
+    for i, hw in enumerate(shapes):
+        Image.fromarray(rng.integers(0, 256, hw + (3,), dtype=np.uint8), mode="RGB").save(str(img_dir / ("im%d.png" % i)))
+    cfg = config.yolov3_tiny_cfg_path
+    layers, _ = od.parse_layers(cfg, 80)
+    wpath = str(tmp_path / "tiny.weights")
+    dw.write_weights(wpath, planner.parse_cfg(cfg, 80)[0], dw.random_params(layers, seed=3))
+    runs = {"b1": dict(batch=1, graph=False), "b2": dict(batch=2, graph=False), "b4g": dict(batch=4, graph=True),
+            "b8": dict(batch=8, graph=False)}
+    found = {}
+    for name, kw in runs.items():
+        args = argparse.Namespace(cfg=cfg, weights=wpath, input_shape=416, dtype=dtype, darknet_model="1", no_splitk=True, **kw)
+        res = inference.run_inference(str(img_dir), str(tmp_path / name), args)
+        found[name] = [len(r[2]) for r in res]
+    assert sum(found["b1"]) > 0
+    for name in ("b2", "b4g", "b8"):
+        assert found[name] == found["b1"]
+        for sub in ("labels", "images"):
+            files = sorted(os.listdir(str(tmp_path / "b1" / sub)))
+            assert len(files) == len(shapes) and files == sorted(os.listdir(str(tmp_path / name / sub)))
+            match, mismatch, errors = filecmp.cmpfiles(str(tmp_path / "b1" / sub), str(tmp_path / name / sub), files, shallow=False)
+            assert not mismatch and not errors, (name, sub, mismatch, errors)
+
+
 @pytest.mark.gpu
 def test_frozen_graph_named_nodes():
     """predict_from_pb.py:221-251 against the node-name shim: fetching scale_1..3 by name with input_image fed

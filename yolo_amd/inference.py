@@ -34,6 +34,8 @@ parser.add_argument("--cfg", default=None, help="darknet .cfg file (default: con
 parser.add_argument("--input_shape", type=int, default=None, help="network input size (default: config.input_shape)")
 parser.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
 parser.add_argument("--no_splitk", action="store_true", help="do not split small launches over k (bit-identical to the batched path)")
+parser.add_argument("--batch", type=int, default=1, help="images per step (default 1, the reference's mode): the directory is processed in "
+                    "chunks of this many images; every image gets the result it gets alone (with --no_splitk bit for bit)")
 parser.add_argument("--graph", action="store_true", help="replay one captured HIP graph per image instead of launching every kernel from the host")
 
 
@@ -177,7 +179,11 @@ def draw_detections(image, out_boxes, out_scores, out_classes, class_names, colo
 
 def run_inference(img_path, output_dir, args):
     """inference.py:170-331: every image of img_path -> output_dir/labels/<stem>.txt and the annotated image
-    under output_dir/images, one image per step, FPS excluding the first image."""
+    under output_dir/images, FPS excluding the first step.  The reference runs one image per step
+    (inference.py:243); `args.batch` = N runs the directory in chunks of N images per step (the last chunk may be
+    shorter).  A batch is B independent batch-1 runs and the batched plan gives an image the same bits
+    whatever the batch size, so the files do not depend on N (tests: byte-identical to batch 1 run with --no_splitk;
+    batch 1 splits small launches over k by default, which adds the partial sums in another order)."""
     for d in (output_dir, os.path.join(output_dir, "images"), os.path.join(output_dir, "labels")):
         if not os.path.exists(d):
             os.mkdir(d)
@@ -190,10 +196,11 @@ def run_inference(img_path, output_dir, args):
     num_classes = config.num_classes
     size = getattr(args, "input_shape", None) or config.input_shape
     input_shape = (size, size)
+    batch = max(1, int(getattr(args, "batch", 1) or 1))
 
     # one image per step: launches with few output tiles are split over k (1.6 -> ~1 ms per 608 image)
     output_nodes = yolo(input_images=None, is_training=False, config_path=cfg_path, num_classes=num_classes,
-                        dtype=getattr(args, "dtype", None), splitk=not getattr(args, "no_splitk", False))
+                        dtype=getattr(args, "dtype", None), splitk=batch == 1 and not getattr(args, "no_splitk", False))
     weights = getattr(args, "weights", None) or config.yolov3_weights_path
     if getattr(args, "darknet_model", None) is None and getattr(args, "weights", None) is None:
         raise NotImplementedError("only Darknet .weights are supported (pass --darknet_model 1); the TF-checkpoint "
@@ -203,45 +210,56 @@ def run_inference(img_path, output_dir, args):
     colors = class_colors(len(class_names))
     total_time_pred = []
     results = []
-    # One image per step, like the reference (inference.py:243).  --graph captures the ~80 launches of a step once
-    # as a HIP graph and replays it per image (graph.GraphedDetector): one submission per image, same results;
-    # measured latency is the same 1.58 ms at 608 (the step is bound by its chain of small kernels, not the host).
+    # --graph captures the ~80 launches of a step once as a HIP graph and replays it per step
+    # (graph.GraphedDetector): one submission per step, same results; measured latency at batch 1 is the same
+    # 1.58 ms at 608 (the step is bound by its chain of small kernels, not the host).
     graphed = None
     if getattr(args, "graph", False):
         from .graph import GraphedDetector
-        graphed = GraphedDetector(output_nodes.net, anchors, num_classes, input_shape, batch=1,
+        graphed = GraphedDetector(output_nodes.net, anchors, num_classes, input_shape, batch=batch,
                                   score_threshold=config.score_threshold, iou_threshold=config.nms_threshold,
                                   max_boxes=config.max_boxes)
-    for x, image in enumerate(images_batch):
-        print("Image height: {}\tImage width: {}".format(image.shape[0], image.shape[1]))
-        hw = [image.shape[0], image.shape[1]]
+    staged = None if graphed is not None else torch.zeros((batch,) + input_shape + (3,), dtype=torch.float32,
+                                                          device=output_nodes.net.device)
+    for first in range(0, len(images_batch), batch):
+        chunk = images_batch[first:first + batch]
+        n = len(chunk)
+        hws = [[im.shape[0], im.shape[1]] for im in chunk]
+        for im in chunk:
+            print("Image height: {}\tImage width: {}".format(im.shape[0], im.shape[1]))
         # resize_image + /255. (inference.py:238-243) on the device: same pixels as the host path
+        target = graphed.images if graphed is not None else staged
+        for j, im in enumerate(chunk):
+            letterbox_gpu(im, input_shape, out=target[j])
         if graphed is not None:
-            letterbox_gpu(image, input_shape, out=graphed.images[0])
+            # a short last chunk replays the full-batch graph: the unused slots keep the previous chunk's images,
+            # whose results are ignored (images are independent)
             tick = time()
-            graphed(hw)
-            out_boxes, out_scores, out_classes = graphed.image(0)
+            graphed(hws + [hws[-1]] * (batch - n))
+            triples = [graphed.image(j) for j in range(n)]
         else:
-            img = letterbox_gpu(image, input_shape).unsqueeze(0)
             tick = time()
-            heads = output_nodes(img)
-            out_boxes, out_scores, out_classes = predict(heads, anchors, num_classes, input_shape, hw)
-            out_boxes, out_scores, out_classes = (t.cpu().numpy() for t in (out_boxes, out_scores, out_classes))
+            heads = output_nodes(staged[:n])
+            det = predict(heads, anchors, num_classes, input_shape, hws[0] if n == 1 else np.asarray(hws))
+            det = [det] if n == 1 else det
+            triples = [tuple(t.cpu().numpy() for t in d) for d in det]
         tock = time()
-        total_time_pred.append(tock - tick)
-        print("Found {} boxes for {} in {}sec".format(len(out_boxes), "img", tock - tick))
-        lines = label_lines(out_boxes, out_scores, out_classes, image.shape[:2])
-        for i, c in reversed(list(enumerate(out_classes))):
-            print("{} {:.4f}".format(class_names[c], out_scores[i]))
-        with open(os.path.join(output_dir, "labels", file_names[x].split(".")[0] + ".txt"), "w") as fh:
-            fh.write("".join(l + "\n" for l in lines))
-        draw_detections(image, out_boxes, out_scores, out_classes, class_names, colors).save(
-            os.path.join(output_dir, "images", file_names[x]), compress_level=1)
-        results.append((out_boxes, out_scores, out_classes))
-    if len(images_batch) > 1:
-        t = sum(total_time_pred[1:])
-        print("FPS of model with post processing over {} images is {}".format(len(images_batch) - 1,
-                                                                             (len(images_batch) - 1) / t))
+        total_time_pred.append((tock - tick, n))
+        for j, (image, (out_boxes, out_scores, out_classes)) in enumerate(zip(chunk, triples)):
+            x = first + j
+            print("Found {} boxes for {} in {}sec".format(len(out_boxes), "img", (tock - tick) / n))
+            lines = label_lines(out_boxes, out_scores, out_classes, image.shape[:2])
+            for i, c in reversed(list(enumerate(out_classes))):
+                print("{} {:.4f}".format(class_names[c], out_scores[i]))
+            with open(os.path.join(output_dir, "labels", file_names[x].split(".")[0] + ".txt"), "w") as fh:
+                fh.write("".join(l + "\n" for l in lines))
+            draw_detections(image, out_boxes, out_scores, out_classes, class_names, colors).save(
+                os.path.join(output_dir, "images", file_names[x]), compress_level=1)
+            results.append((out_boxes, out_scores, out_classes))
+    if len(total_time_pred) > 1:
+        t = sum(dt for dt, _ in total_time_pred[1:])
+        n = sum(k for _, k in total_time_pred[1:])
+        print("FPS of model with post processing over {} images is {}".format(n, n / t))
     return results
 
 
