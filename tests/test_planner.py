@@ -155,3 +155,29 @@ def test_residual_blocks_fuse_into_one_op():
     assert not any(op["kind"] == "resblock" for op in planner.build_plan(layers, oi, 64, 416, 416, "bf16").ops)
     small = planner.build_plan(layers, oi, 64, 608, 608, "bf16", resblock=False)
     assert big.arena_bytes <= small.arena_bytes
+
+
+def test_inplace_shortcuts_alias_the_dead_operand():
+    """A convolution with a fused shortcut writes its sum over the shortcut operand when that is the operand's last
+    use (18 of YOLOv3's 23 shortcuts: not the stem's, not the two whose operand a later route reads... and the numpy
+    interpreter, which executes the aliasing for real, still reproduces the oracle)."""
+    cfg = config.yolov3_cfg_path
+    layers, oi = planner.parse_cfg(cfg, 80)
+    def aliased(plan):
+        return [op["writes_layer"] for op in plan.ops
+                if op.get("res") is not None and (op["res"]["buf"], op["res"]["off"]) == (op["y"]["buf"], op["y"]["off"])]
+    on = planner.build_plan(layers, oi, 2, 160, 160, "fp32", inplace_shortcut=True)
+    off = planner.build_plan(layers, oi, 2, 160, 160, "fp32", inplace_shortcut=False)
+    assert aliased(off) == [] and len(aliased(on)) >= 18
+    # a shortcut operand that a later layer still reads keeps its own storage: layer 36 and 61 feed the head branches
+    for op in on.ops:
+        if op.get("res") is not None and op["writes_layer"] in aliased(on):
+            src = layers[op["writes_layer"]]["src"]
+            assert src not in (36, 61)
+    ol, ooi = od.parse_layers(cfg, 80)
+    params = dw.random_params(layers, seed=12)
+    x = np.random.default_rng(2).random((2, 160, 160, 3), dtype=np.float32)
+    ref = od.forward(ol, ooi, params, x)
+    for a, b in zip(plan_sim.Sim(on, layers, params, x).run(), ref):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4)
+    assert on.arena_bytes <= off.arena_bytes

@@ -236,8 +236,10 @@ def find_resblocks(layers, inputs, uses, head_of, shapes, batch, dtype, mode, ch
 
 
 def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=True, pad_input=False, stem=True,
-               snake=True, resblock=None):
+               snake=True, resblock=None, inplace_shortcut=None):
     assert dtype in ("bf16", "fp32")
+    if inplace_shortcut is None:
+        inplace_shortcut = os.environ.get("YOLO_AMD_INPLACE", "1") != "0"
     es = 2 if dtype == "bf16" else 4
     epc = 16 // es
     shapes = infer_shapes(layers, in_h, in_w, in_c)
@@ -342,6 +344,33 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
                 claimed[j] = (b, off, ld)
             off += cj
 
+    # In-place shortcuts.  A convolution with a fused shortcut reads its residual operand R and writes the sum element for
+    # element (same lane, load before store, in every epilogue), so when the sum is R's last use the two share storage:
+    # the stores hit lines the loads just brought in, and the working set of a residual stage shrinks by one tensor
+    # (at 76x76, batch 64: 473 -> 284 MB against the 256 MiB Infinity Cache).  Not for the fused block kernel, whose
+    # tiles read their neighbours' pixels of x (halo).
+    inplace = {}
+    if fuse and inplace_shortcut:
+        users = [[] for _ in range(n)]
+        for j, ins in enumerate(inputs):
+            for q in ins:
+                if q is not None and q >= 0:
+                    users[q].append(j)
+        for i, p in fused_into.items():
+            L = layers[i]
+            if L["type"] != "shortcut" or p in resblocks:
+                continue
+            src = L["src"]
+            if src < 0 or src in claimed or src in head_of or i in claimed or i in head_of or shapes[src] != shapes[i]:
+                continue
+            if layers[src]["type"] == "route" or (stem_layers is not None and src in stem_layers):
+                continue
+            if src in absorbed or src in rb_internal or inputs[p] == [src]:
+                continue
+            if any(j != i and j >= p for j in users[src]):
+                continue                       # someone reads R after the sum is written (a route to a head branch)
+            inplace[i] = src
+
     for i, L in enumerate(layers):
         t = L["type"]
         if t == "yolo" or i in absorbed or i in rb_internal or (stem_layers is not None and i == stem_layers[0]):
@@ -362,6 +391,8 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
         elif i in claimed:
             b, off, ld = claimed[i]
             tens[i] = dict(buf=b, off=off, ld=ld, c=c)
+        elif i in inplace:
+            tens[i] = dict(tens[inplace[i]])     # the shortcut's sum overwrites its (dead) shortcut operand
         else:
             ld = _ceil_to(c, epc)
             tens[i] = dict(buf=new_buf(pixels(i) * ld), off=0, ld=ld, c=c)
