@@ -1,7 +1,7 @@
 /* yolo3hip_experimental.h -- knobs of libyolo3hip_exp.so, the -DY3_EXPERIMENTS flavour of libyolo3hip.so.
  *
  * NOT part of the product ABI and absent from libyolo3hip.so.  The experimental flavour is the same source built
- * with -DY3_EXPERIMENTS; it exports everything include/yolo3hip.h declares plus the setters below, which write
+ * with -DY3_EXPERIMENTS; it exports everything include/yolo3hip.h declares plus the functions below; the setters write
  * plain process-global variables read by every later launch on every thread (set them from one thread, between
  * launches).  Users: the tile-equality and kernel-variant tests (tests/test_gpu_conv.py, tests/test_gpu_decode.py),
  * tools/layer_report.py --tile/--phase and the A/B scripts under tools/.  The reference has no counterpart.
@@ -26,6 +26,17 @@ int y3_set_conv_phase(int percent);
 int y3_set_conv_cus(int cus);
 /* 1 = always the 16-lanes-per-box decode kernel, 0 = automatic (lane-per-box when shapes allow). */
 int y3_decode_variant(int v);
+
+/* The all-pairs IoU bitmask form of per-class NMS (BASELINE north_star's sketch), kept for the A/B against the greedy
+ * kernels of y3_nms_bucketed (tools/nms_ab.py): bucket -> bitonic sort of each pair's candidates -> one
+ * 64-bit mask word per (row, 64-candidate column block) -> one wavefront per pair scans with the suppressed set in
+ * registers.  Same kept indices as y3_nms_bucketed (tests/test_gpu_nms.py).  workspace: y3_nms_workspace_ints() ints;
+ * mask: batch * mask_words_per_image 64-bit words, an image needs sum over classes of n * ceil(n / 64); status[b] = 1
+ * (and nothing kept for image b) when its masks do not fit, a class has more than 8192 candidates or bucketing failed. */
+int y3_nms_bitmask(const float *records, const int32_t *cand_idx, const int32_t *cand_count, const int32_t *class_count,
+                   int batch, int boxes_per_image, int num_classes, int max_boxes, float iou_threshold,
+                   int32_t *workspace, uint64_t *mask, int64_t mask_words_per_image, int32_t *status,
+                   int32_t *kept_idx, int32_t *kept_count, void *stream);
 
 #ifdef __cplusplus
 }

@@ -202,3 +202,32 @@ def _run_nms(per_image, num_classes, max_boxes, iou_thr, with_rank, bucketed):
     torch.cuda.synchronize()
     return dict(kept_idx=kept_idx.cpu().numpy(), kept_rank=kept_rank.cpu().numpy(), kept_count=kept_count.cpu().numpy(),
                 boxes=ob.cpu().numpy(), scores=os_.cpu().numpy(), classes=oc.cpu().numpy(), count=on.cpu().numpy())
+
+
+def run_nms_bitmask(per_image, num_classes, max_boxes, iou_thr, mask_words=None):
+    """The experimental all-pairs bitmask NMS (libyolo3hip_exp.so: y3_nms_bitmask) on the input format of run_nms.
+    Returns kept_idx [B,C,max_boxes], kept_count [B,C], status [B]."""
+    with _lib.experimental() as lib:
+        B = len(per_image)
+        N = per_image[0][0].shape[0]
+        rec = torch.from_numpy(np.stack([p[0] for p in per_image])).cuda()
+        cand = np.zeros((B, N), dtype=np.int32)
+        cc = np.zeros(B, dtype=np.int32)
+        clc = np.zeros((B, num_classes), dtype=np.int32)
+        for b, (_, c, k) in enumerate(per_image):
+            cand[b, :len(c)] = c
+            cc[b] = len(c)
+            clc[b] = k
+        if mask_words is None:
+            mask_words = int(max(1, (clc.astype(np.int64) * ((clc + 63) // 64)).sum(axis=1).max()))
+        cand_t, cc_t, clc_t = (torch.from_numpy(a).cuda() for a in (cand, cc, clc))
+        kept_idx = torch.full((B, num_classes, max_boxes), -1, dtype=torch.int32, device="cuda")
+        kept_count = torch.full((B, num_classes), -1, dtype=torch.int32, device="cuda")
+        status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        wsp = torch.full((int(lib.y3_nms_workspace_ints(B, N)),), 12345, dtype=torch.int32, device="cuda")
+        mask = torch.full((B * mask_words,), -1, dtype=torch.int64, device="cuda")
+        _lib.check(lib.y3_nms_bitmask(rec.data_ptr(), cand_t.data_ptr(), cc_t.data_ptr(), clc_t.data_ptr(), B, N, num_classes,
+                                      max_boxes, float(np.float32(iou_thr)), wsp.data_ptr(), mask.data_ptr(), mask_words,
+                                      status.data_ptr(), kept_idx.data_ptr(), kept_count.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        return dict(kept_idx=kept_idx.cpu().numpy(), kept_count=kept_count.cpu().numpy(), status=status.cpu().numpy())

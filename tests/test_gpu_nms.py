@@ -140,3 +140,26 @@ def test_nms_crowded_classes_lds_cached_path():
         got_rank = np.concatenate([out["kept_rank"][i, c, :out["kept_count"][i, c]] for c in range(C)])
         np.testing.assert_array_equal(got_pool, opool)
         np.testing.assert_array_equal(got_rank, orank)
+
+
+@pytest.mark.parametrize("n,C,thr_s,ties", [(500, 80, 0.3, False), (3000, 80, 0.001, True), (2535, 3, 0.05, True),
+                                             (10647, 80, 0.001, False), (22743, 4, 0.001, True)])
+def test_bitmask_nms_keeps_the_same_indices(n, C, thr_s, ties):
+    """The all-pairs IoU bitmask + scan form of NMS (north_star's sketch; experimental flavour only, kept for the A/B
+    of DESIGN.md 3.5) keeps exactly the indices of the greedy kernels, ties and crowded classes (thousands of
+    candidates per pair: many 64-wide column blocks, multi-pass bitonic sorts) included."""
+    rng = np.random.default_rng(n + C)
+    scenes = [_random_scene(rng, n, C, ties) for _ in range(2)]
+    recs = [gpu_util.records_from_dense(b, d, thr_s) for b, d in scenes]
+    want = gpu_util.run_nms(recs, C, 51, 0.3, with_rank=False)
+    got = gpu_util.run_nms_bitmask(recs, C, 51, 0.3)
+    assert (got["status"] == 0).all()
+    np.testing.assert_array_equal(got["kept_count"], want["kept_count"])
+    assert want["kept_count"].sum() > 0
+    for b in range(len(scenes)):
+        for c in range(C):
+            k = want["kept_count"][b, c]
+            np.testing.assert_array_equal(got["kept_idx"][b, c, :k], want["kept_idx"][b, c, :k])
+    # masks that do not fit are reported, not overrun
+    small = gpu_util.run_nms_bitmask(recs, C, 51, 0.3, mask_words=8)
+    assert (small["status"] == 1).all() and (small["kept_count"] == 0).all()

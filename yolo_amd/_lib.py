@@ -76,6 +76,8 @@ EXPERIMENTAL_SIGNATURES = {
     "y3_set_conv_phase": (c_int, [c_int]),
     "y3_set_conv_cus": (c_int, [c_int]),
     "y3_decode_variant": (c_int, [c_int]),
+    "y3_nms_bitmask": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32,
+                               c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

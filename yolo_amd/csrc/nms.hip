@@ -595,6 +595,215 @@ extern "C" int y3_nms_bucketed_static(const float *records, const int32_t *cand_
                       ws, kept_idx, kept_rank, kept_count, (hipStream_t)stream);
 }
 
+#ifdef Y3_EXPERIMENTS
+// ---- libyolo3hip_exp.so only: the all-pairs IoU bitmask form of per-class NMS, for the A/B in DESIGN.md 3.5 -------
+// BASELINE's north_star sketches NMS as "a wavefront-level IoU bitmask kernel with an LDS-resident suppression scan".
+// This is that algorithm, written to be fast, so that the choice of the greedy-round kernels above rests on a
+// measurement (tools/nms_ab.py) and not only on the operation count:
+//   (1) bm_sort_kernel   a workgroup sorts a pair's candidates by (score desc, index asc) -- bitonic sort of the 64-bit
+//                        keys in LDS -- and writes the order back over the pair's bucket list;
+//   (2) bm_mask_kernel   a workgroup takes 256 rows of a pair's n x n matrix: lane = row i, and for every 64-candidate
+//                        column block at or right of its own (staged in LDS, read as broadcasts) 64 IoU tests ->
+//                        one 64-bit word mask[i][cb], bit jj = "j = 64 cb + jj > i and IoU(i, j) > thr";
+//   (3) bm_scan_kernel   one wavefront per pair: the suppressed-set bitmap lives in registers (two words per lane);
+//                        at most max_boxes times {first candidate not suppressed (ffs + wave minimum), keep it, OR its
+//                        mask row into the bitmap}.
+// Same order and the same predicate (iou_gt_norm) as the greedy kernels, hence the same kept indices.  n <= 8192 per
+// pair; the masks of an image must fit mask_words_per_image 64-bit words (status[b] = 1 otherwise, nothing kept).
+namespace {
+
+constexpr int kBmMaxN = 8192;
+constexpr int kBmRows = 256;            // rows of a pair's matrix per bm_mask_kernel work item
+
+__device__ __forceinline__ long bm_pair_offset(const int *class_count, int b, int C, int c, long *total) {
+    long off = 0, acc = 0;
+    for (int q = 0; q < C; ++q) {
+        const long n = class_count[b * C + q];
+        if (q == c) off = acc;
+        acc += n * ((n + 63) >> 6);
+    }
+    *total = acc;
+    return off;
+}
+
+__global__ __launch_bounds__(kThreads) void bm_sort_kernel(const float *records, const int *class_count, int *ws, int ws_stride,
+                                                           int B, int N, int C, long mask_words, int *status) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *keys = (unsigned long long *)smem;
+    const int tid = threadIdx.x;
+    for (int slot = blockIdx.x; slot < B * C; slot += gridDim.x) {
+        const int c = slot / B, b = slot - c * B;                // class-major, as nms_kernel
+        const int n = class_count[b * C + c];
+        int *wsb = ws + (long)b * ws_stride;
+        if (c == 0 && tid == 0) {
+            long total;
+            bm_pair_offset(class_count, b, C, 0, &total);
+            int bad = total > mask_words || wsb[0] < 0;
+            for (int q = 0; q < C; ++q) bad |= class_count[b * C + q] > kBmMaxN;
+            status[b] = bad;
+        }
+        if (n < 2 || n > kBmMaxN || wsb[0] < 0) continue;        // block-uniform
+        int *list = wsb + kWsHeader + wsb[c];
+        const float *rec = records + (long)b * N * 8;
+        int P = 2;
+        while (P < n) P <<= 1;
+        __syncthreads();                                         // previous pair's LDS use is over
+        for (int i = tid; i < P; i += kThreads) {
+            unsigned long long k = 0ull;
+            if (i < n) { const int idx = list[i]; k = make_key(rec[(long)idx * 8 + 4], idx); }
+            keys[i] = k;
+        }
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (P >> 1); t += kThreads) {
+                    const int i = 2 * t - (t & (j - 1)), l = i + j;
+                    const bool desc = (i & k) == 0;
+                    const unsigned long long a = keys[i], bb = keys[l];
+                    if ((a < bb) == desc) { keys[i] = bb; keys[l] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < n; i += kThreads) list[i] = (int)(~(unsigned)keys[i]);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bm_mask_kernel(const float *records, const int *class_count, const int *ws,
+                                                           int ws_stride, int B, int N, int C, float thr,
+                                                           unsigned long long *mask, long mask_words, const int *status) {
+    __shared__ f32x4 s_col[4][64];                               // a column block's boxes, corners ordered
+    __shared__ float s_area[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kSplit = 8;            // workgroups that share a pair: work item (pair, s) takes row chunks s, s + 8, ...
+    for (long item = blockIdx.x; item < (long)B * C * kSplit; item += gridDim.x) {
+        const int s0 = (int)(item % kSplit);
+        const int slot = (int)(item / kSplit);
+        const int c = slot / B, b = slot - c * B;
+        const int n = class_count[b * C + c];
+        if (s0 * kBmRows >= n || n < 2 || status[b]) continue;               // block-uniform
+        const int *wsb = ws + (long)b * ws_stride;
+        const int *list = wsb + kWsHeader + wsb[c];
+        const float *rec = records + (long)b * N * 8;
+        const int W = (n + 63) >> 6;
+        long total;
+        unsigned long long *m = mask + (long)b * mask_words + bm_pair_offset(class_count, b, C, c, &total);
+        for (int chunk = s0; chunk * kBmRows < n; chunk += kSplit) {
+            const int rb = chunk * (kBmRows / 64) + wave;                    // this wave's row block
+            if (rb >= W) continue;                                           // wave-uniform; no workgroup barrier below
+            const int i = rb * 64 + lane;
+            const NBox bi = norm_box(*(const f32x4 *)(rec + (long)list[i < n ? i : 0] * 8));
+            for (int cb = rb; cb < W; ++cb) {
+                const int jl = cb * 64 + lane;
+                const NBox bl = norm_box(*(const f32x4 *)(rec + (long)list[jl < n ? jl : 0] * 8));
+                s_col[wave][lane] = f32x4{bl.ymin, bl.xmin, bl.ymax, bl.xmax};
+                s_area[wave][lane] = bl.area;
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long word = 0ull;
+                const int jn = min(64, n - cb * 64);
+                for (int jj = 0; jj < jn; ++jj) {
+                    const f32x4 q = s_col[wave][jj];
+                    NBox bj;
+                    bj.ymin = q[0]; bj.xmin = q[1]; bj.ymax = q[2]; bj.xmax = q[3]; bj.area = s_area[wave][jj];
+                    const bool hit = (cb * 64 + jj > i) & iou_gt_norm(bj, bi, thr);
+                    word |= (unsigned long long)hit << jj;
+                }
+                if (i < n) m[(long)i * W + cb] = word;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bm_scan_kernel(const int *class_count, const int *ws, int ws_stride, int B, int C,
+                                                           int max_boxes, const unsigned long long *mask, long mask_words,
+                                                           const int *status, int *kept_idx, int *kept_count) {
+    const int lane = threadIdx.x & 63;
+    const int wave0 = (blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = (gridDim.x * kThreads) >> 6;
+    for (int pair = wave0; pair < B * C; pair += nwaves) {
+        const int b = pair / C, c = pair - b * C;
+        const int n = __builtin_amdgcn_readfirstlane(class_count[pair]);
+        int *kidx = kept_idx + (long)pair * max_boxes;
+        if (n == 0 || __builtin_amdgcn_readfirstlane(status[b])) {
+            if (lane == 0) kept_count[pair] = 0;
+            continue;
+        }
+        const int *wsb = ws + (long)b * ws_stride;
+        const int *list = wsb + kWsHeader + __builtin_amdgcn_readfirstlane(wsb[c]);
+        const int W = (n + 63) >> 6;
+        long total;
+        const unsigned long long *m = mask + (long)b * mask_words + bm_pair_offset(class_count, b, C, c, &total);
+        // suppressed-set bitmap: lane l holds words l and l + 64; bits at or beyond n start out set
+        unsigned long long rem[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int w = lane + 64 * q;
+            const int valid = n - w * 64;                        // candidates in word w
+            rem[q] = valid >= 64 ? 0ull : (valid <= 0 ? ~0ull : (~0ull << valid));
+        }
+        int kept = 0;
+        while (kept < max_boxes) {
+            int first = 0x7fffffff;                              // first candidate of this lane's words that is still alive
+#pragma unroll
+            for (int q = 1; q >= 0; --q)
+                if (~rem[q] != 0ull) first = (lane + 64 * q) * 64 + __ffsll((unsigned long long)~rem[q]) - 1;
+            // wave minimum: the keys' DPP maximum on the complemented value
+            const unsigned long long best = wave_max_u64((unsigned long long)(unsigned)(0x7fffffff - first));
+            const int i = 0x7fffffff - (int)(unsigned)best;
+            if (i >= n) break;                                   // nothing alive (wave-uniform)
+            if (lane == 0) kidx[kept] = list[i];
+            ++kept;
+            const int rb = i >> 6;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int w = lane + 64 * q;
+                unsigned long long row = 0ull;
+                if (w >= rb && w < W) row = m[(long)i * W + w];
+                if (w == rb) row |= 1ull << (i & 63);            // the kept candidate itself leaves the alive set
+                rem[q] |= row;
+            }
+        }
+        if (lane == 0) kept_count[pair] = kept;
+    }
+}
+
+}  // namespace
+
+extern "C" int y3_nms_bitmask(const float *records, const int32_t *cand_idx, const int32_t *cand_count, const int32_t *class_count,
+                              int batch, int boxes_per_image, int num_classes, int max_boxes, float iou_threshold,
+                              int32_t *workspace, uint64_t *mask, int64_t mask_words_per_image, int32_t *status,
+                              int32_t *kept_idx, int32_t *kept_count, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    Y3_REQUIRE(records && cand_idx && cand_count && class_count && workspace && mask && status && kept_idx && kept_count,
+               Y3_E_INVALID, "nms_bitmask: null pointer");
+    Y3_REQUIRE(batch > 0 && boxes_per_image > 0 && num_classes > 0 && num_classes <= 96 && max_boxes > 0 && mask_words_per_image > 0,
+               Y3_E_INVALID, "nms_bitmask: bad shape");
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        if (hipFuncSetAttribute((const void *)bm_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBmMaxN * 8) != hipSuccess) {
+            y3_set_error("nms_bitmask: cannot reserve LDS");
+            return Y3_E_LAUNCH;
+        }
+        attr_dev = dev;
+    }
+    const int ws_stride = boxes_per_image + kWsHeader;
+    const int pairs = batch * num_classes;
+    hipLaunchKernelGGL(nms_bucket_kernel, dim3(batch), dim3(1024), 0, stream, records, cand_idx, cand_count, class_count,
+                       boxes_per_image, num_classes, workspace, ws_stride);
+    hipLaunchKernelGGL(bm_sort_kernel, dim3(pairs < 512 ? pairs : 512), dim3(kThreads), kBmMaxN * 8, stream, records, class_count,
+                       workspace, ws_stride, batch, boxes_per_image, num_classes, (long)mask_words_per_image, status);
+    hipLaunchKernelGGL(bm_mask_kernel, dim3(2048), dim3(kThreads), 0, stream, records, class_count, workspace, ws_stride, batch,
+                       boxes_per_image, num_classes, iou_threshold, (unsigned long long *)mask, (long)mask_words_per_image, status);
+    int sblocks = (pairs + 3) / 4;
+    if (sblocks > 2048) sblocks = 2048;
+    hipLaunchKernelGGL(bm_scan_kernel, dim3(sblocks), dim3(kThreads), 0, stream, class_count, workspace, ws_stride, batch,
+                       num_classes, max_boxes, (const unsigned long long *)mask, (long)mask_words_per_image, status, kept_idx, kept_count);
+    return y3_check_launch("nms_bitmask");
+}
+#endif  // Y3_EXPERIMENTS
+
 extern "C" int y3_pack_outputs(const float *records, const int32_t *kept_idx, const int32_t *kept_count, int batch,
                                int boxes_per_image, int num_classes, int max_boxes, float *out_boxes,
                                float *out_scores, int32_t *out_classes, int32_t *out_count, void *stream) {
