@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24, help="timed images of the CPU baseline (plus 1 warm-up)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--unfused-decode", action="store_true", help="A/B: write the fp32 heads and run y3_decode on them instead of "
+                    "decoding inside the head convolutions' epilogue")
     ap.add_argument("--event-every", type=int, default=4,
                     help="timed steps that carry HIP events around the dominant kernel's launches: every Nth (an event "
                          "pair costs ~3 us of stream time; 25 pairs on every step slowed the measured step by 1.6 %%)")
@@ -134,17 +136,36 @@ def main():
         graphed.images.copy_(images)
         graphed.capture((S, S))
 
+    pp = inference._postprocessor(anchors, config.num_classes, (S, S))
+
     def step(trace=None, trace_filter=None):
+        # backbone -> decode -> NMS -> pack.  PostProcessor.detect runs each scale's decode inside its head convolution's
+        # epilogue when every head launch qualifies (bf16, 256 / 192-pixel tiles; --unfused-decode turns it off), else
+        # the three fp32 heads are written, and y3_decode reads them back.
         if graphed is not None:
             return graphed()
-        heads = net.forward(images, chunk=chunk, trace=trace, trace_filter=trace_filter)
-        if trace is None or trace_filter is not None:
-            return inference.predict_batch(heads, anchors, config.num_classes, (S, S), (S, S))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()                                   # full trace (warm-up only): decode + NMS + pack as one stage
-        det = inference.predict_batch(heads, anchors, config.num_classes, (S, S), (S, S))
-        e1.record()
-        trace.append(({"kind": "post", "kernel": "decode+nms+pack"}, e0, e1))
+        if args.unfused_decode:
+            heads = net.forward(images, chunk=chunk, trace=trace, trace_filter=trace_filter)
+            det = None
+        full = trace is not None and trace_filter is None
+        if full:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n0 = len(trace)
+        if args.unfused_decode:
+            if full:
+                e0.record()
+            det = inference.predict_batch(heads, anchors, config.num_classes, (S, S), (S, S))
+            if full:
+                e1.record()
+                trace.append(({"kind": "post", "kernel": "decode+nms+pack"}, e0, e1))
+            return det
+        if full:
+            e0.record()
+        det, _ = pp.detect(net, images, (S, S), chunk=chunk, trace=trace, trace_filter=trace_filter)
+        if full:                                      # full trace (warm-up only): what follows the last backbone launch
+            e1.record()
+            trace.append(({"kind": "post", "kernel": "nms+pack (decode is in the head convolutions)", "after": trace[-1][2] if len(trace) > n0 else e0},
+                          e0, e1))
         return det
 
     # Warm-up.  Its last step is traced in full (un-timed) to find the kernel most of the step goes to and the
@@ -244,7 +265,8 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
             w_conv = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] in ("conv", "stem", "resblock"))
-            w_post = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] == "post")
+            w_post = sum((op["after"].elapsed_time(e1) if "after" in op else e0.elapsed_time(e1))
+                         for op, e0, e1 in warm_trace if op["kind"] == "post")
             w_other = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] not in ("conv", "stem", "resblock", "post"))
             out["stage_ms_per_step"] = {"conv_all": round(w_conv, 3), "other_layers": round(w_other, 3),
                                         "decode_nms_pack": round(w_post, 3),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define Y3_VERSION 101
+#define Y3_VERSION 102
 
 enum { Y3_F32 = 0, Y3_BF16 = 1 };
 
@@ -175,6 +175,20 @@ typedef struct y3_decode_desc {
 int y3_decode(const y3_decode_desc *desc, const float *head0, const float *head1, const float *head2,
               const float *letterbox, float *records, int32_t *cand_idx, int32_t *cand_count,
               int32_t *class_count, void *stream);
+
+/* A head convolution (build_model.py:113-179 on the 1x1 that feeds a [yolo] section) with the decode of ITS scale
+ * (utils/utils.py:43-160, inference.py:110-127: exactly what y3_decode does for scale `scale` of `desc`) fused into
+ * the epilogue: the finished fp32 head values are decoded where they are staged for the store, with y3_decode's own
+ * per-box code, so records / candidates / counts are those y3_decode would produce (candidate order aside, which
+ * nothing depends on).  `out` (fp32 [B,g,g,n_pad]) may be NULL: then the head tensor itself is never written.
+ * Calling it for every scale of `desc` replaces the y3_decode call; cand_count / class_count zeroed beforehand as
+ * for y3_decode.  Only for launches that run on the 256- or 192-pixel x 256-channel tiles (bf16 network, 3 anchors,
+ * <= 80 classes, large batch): y3_conv_head_decode_ok (host only) tells, and a host falls back to
+ * y3_conv2d_fused + y3_decode for ALL scales when any of them does not qualify. */
+int y3_conv_head_decode_ok(const y3_conv_desc *conv, const y3_decode_desc *desc, int scale);
+int y3_conv2d_head_decode(const y3_conv_desc *conv, const void *in, const void *w, const float *bias, void *out,
+                          const void *zero_page, const y3_decode_desc *desc, int scale, const float *letterbox,
+                          float *records, int32_t *cand_idx, int32_t *cand_count, int32_t *class_count, void *stream);
 
 /* Dense forms kept for API parity with the reference's helper functions. */
 /* get_head (utils/utils.py:43-96) for one scale: xy,wh [cells*A*2], conf [cells*A], cls [cells*A*C]. */

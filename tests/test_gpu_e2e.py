@@ -351,6 +351,60 @@ def test_run_inference_batched_writes_the_same_files(tmp_path, dtype):
             assert not mismatch and not errors, (name, sub, mismatch, errors)
 
 
+@pytest.mark.parametrize("size,batch,chunk,thr", [(608, 24, None, 0.6), (416, 120, 64, 0.3), (608, 32, None, 0.001)])
+def test_head_decode_fused_into_the_head_convolutions(size, batch, chunk, thr):
+    """PostProcessor.detect runs each scale's decode inside its head convolution's epilogue (y3_conv2d_head_decode) when
+    every head launch qualifies: the records, the candidate SET, the class counts, the heads (when asked for) and the
+    final detections are bit-identical to backbone + y3_decode, chunked batches and the dense-stress threshold
+    included; without want_heads the head tensors are not produced at all.  Small launches fall back."""
+    from yolo_amd.postprocess import PostProcessor
+    cfg = config.yolov3_cfg_path
+    layers, _ = od.parse_layers(cfg, 80)
+    net = build_model.Network(cfg, 80, dtype="bf16")
+    net.set_params(dw.random_params(layers, seed=21))
+    anchors = inference.read_anchors(config.anchors_path)
+    x = torch.rand((batch, size, size, 3), dtype=torch.float32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(size + batch))
+    shapes = np.stack([np.array([300 + 7 * i, 500 - 5 * i]) for i in range(batch)])
+    plain = PostProcessor(anchors, 80, (size, size), thr, 0.3, 51)
+    heads = net.forward(x, chunk=chunk)
+    want = plain(heads, shapes)
+    w_rec, w_cnt = want.records.clone(), plain._workspace(batch, want.records.shape[1], x.device)["counts"].clone()
+    w_cand = plain._workspace(batch, want.records.shape[1], x.device)["cand_idx"].clone()
+    w_out = [t.clone() for t in (want.boxes, want.scores, want.classes, want.count)]
+    fused = PostProcessor(anchors, 80, (size, size), thr, 0.3, 51)
+    for want_heads in (True, False):
+        dec = dict(pp=fused, ws=None, store_heads=want_heads)
+        got, gh = fused.detect(net, x, shapes, chunk=chunk, want_heads=want_heads)
+        step = batch if not chunk else chunk
+        assert all(net.plan_for(nb, size, size).decode_launchers(fused)[1] is not None for nb in {step, batch % step or step}), "fused path not taken"
+        ws = fused._workspace(batch, got.records.shape[1], x.device)
+        torch.testing.assert_close(got.records, w_rec, rtol=0, atol=0)
+        torch.testing.assert_close(ws["counts"], w_cnt, rtol=0, atol=0)
+        cc = w_cnt[:batch].cpu().numpy()
+        a, b = ws["cand_idx"].cpu().numpy(), w_cand.cpu().numpy()
+        for i in range(batch):
+            assert sorted(a[i, :cc[i]]) == sorted(b[i, :cc[i]])
+        torch.testing.assert_close(got.count, w_out[3], rtol=0, atol=0)
+        for i, m in enumerate(w_out[3].cpu().numpy()):             # (the padded tails are uninitialised memory)
+            for g, w in zip((got.boxes, got.scores, got.classes), w_out[:3]):
+                torch.testing.assert_close(g[i, :m], w[i, :m], rtol=0, atol=0)
+        if want_heads:
+            for g, w in zip(gh, heads):
+                torch.testing.assert_close(g, w, rtol=0, atol=0)
+        else:
+            assert gh is None
+    assert int(w_out[3].sum()) > 0
+    # a launch too small for the big tiles: detect falls back to y3_decode, same detections
+    small = x[:2]
+    d1, _ = fused.detect(net, small, shapes[:2])
+    assert net.plan_for(2, size, size).decode_launchers(fused)[1] is None
+    b1, c1 = d1.boxes.clone(), d1.count.clone()
+    d2 = plain(net.forward(small), shapes[:2])
+    torch.testing.assert_close(c1, d2.count, rtol=0, atol=0)
+    for i, m in enumerate(c1.cpu().numpy()):
+        torch.testing.assert_close(b1[i, :m], d2.boxes[i, :m], rtol=0, atol=0)
+
+
 @pytest.mark.gpu
 def test_frozen_graph_named_nodes():
     """predict_from_pb.py:221-251 against the node-name shim: fetching scale_1..3 by name with input_image fed

@@ -52,6 +52,9 @@ SIGNATURES = {
     "y3_copy_channels": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
     "y3_shortcut_add": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp]),
     "y3_decode": (c_int, [ctypes.POINTER(DecodeDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_conv_head_decode_ok": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(DecodeDesc), c_int]),
+    "y3_conv2d_head_decode": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(DecodeDesc), c_int,
+                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "y3_get_head": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32, c_f32,
                             c_vp, c_vp, c_vp, c_vp, c_vp]),
     "y3_correct_boxes": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp]),

@@ -77,7 +77,36 @@ class _CompiledPlan(object):
                     need = max(need, self._splitk_bytes(net, op))
         if need:
             self._splitk_ws = torch.empty(need, dtype=torch.uint8, device=net.device)
+        self.head_ops = {}              # head index -> what a fused head-decode launch of that op needs (_prepare)
+        self._decode = {}               # PostProcessor id -> (DecodeDesc for this plan's batch, fused launchers or None)
         self.launchers = [self._prepare(net, op) for op in plan.ops]
+
+    def decode_launchers(self, pp):
+        """Launch list of this plan with the YOLO decode fused into the head convolutions (y3_conv2d_head_decode), for
+        the thresholds / anchors of PostProcessor `pp`, or None when a head launch does not qualify (small batches,
+        fp32 mode, 2-anchor heads ...): then the caller runs the plain plan and y3_decode.  Returns (desc, launchers)."""
+        key = id(pp)
+        hit = self._decode.get(key)
+        if hit is None:
+            lib = _lib.load()
+            heads = self.plan.heads
+            d = pp.describe(self.plan.batch, [(h["h"], h["w"], h["ld"]) for h in heads])
+            ok = len(self.head_ops) == len(heads) and all(
+                lib.y3_conv_head_decode_ok(self.head_ops[k]["dref"], ctypes.byref(d), k) for k in range(len(heads)))
+            launchers = None
+            if ok:
+                launchers = list(self.launchers)
+                fn = lib.y3_conv2d_head_decode
+                for k, ho in self.head_ops.items():
+                    def launch(env, _ho=ho, _k=k, _d=d, _dref=ctypes.byref(d)):
+                        dec = env["decode"]
+                        return fn(_ho["dref"], _ho["x"](env), _ho["w"], _ho["b"], _ho["y"](env) if dec["store_heads"] else None,
+                                  _ho["z"], _dref, _k, dec["letterbox"], dec["records"], dec["cand_idx"], dec["cand_count"],
+                                  dec["class_count"], env["stream"])
+                    launchers[ho["index"]] = launch
+            hit = (d, launchers, pp)      # (pp kept so that id(pp) stays unique while the entry lives)
+            self._decode[key] = hit
+        return hit[0], hit[1]
 
     def splitk_workspace(self, net, nbytes):
         assert self._splitk_ws is not None and self._splitk_ws.numel() >= nbytes
@@ -165,6 +194,9 @@ class _CompiledPlan(object):
                     def launch_split(env, _keep=(d, w, bias, ws)):
                         return fk(dref, x(env), wp, bp, r(env), y(env), zp, wsp, wsn, env["stream"])
                     return launch_split
+
+            if op["out_f32"] and op["y"]["buf"][0] == "head" and not net.splitk:
+                self.head_ops[op["y"]["buf"][1]] = dict(dref=dref, x=x, y=y, w=wp, b=bp, z=zp, index=plan.ops.index(op), keep=(d, w, bias))
 
             def launch(env, _keep=(d, w, bias)):
                 return fn(dref, x(env), wp, bp, r(env), y(env), zp, env["stream"])
@@ -316,13 +348,17 @@ class Network(object):
             self._plans[key] = cp
         return cp
 
-    def forward(self, images, chunk=None, trace=None, trace_filter=None):
+    def forward(self, images, chunk=None, trace=None, trace_filter=None, decode=None):
         """images: float32 NHWC [B,H,W,3] on this network's device, values as the reference
         feeds them (image/255, inference.py:242).  Returns the head tensors (fp32,
         [B,g,g,3*(C+5)] views, coarse -> fine).  `chunk` splits the batch into sub-batches
         that run back to back through the whole plan.  `trace`, if a list, receives
         (op, start_event, end_event) for every launch (HIP events on the launch stream), or only for
-        the launches trace_filter(op) selects (an event pair costs ~3 us of stream time)."""
+        the launches trace_filter(op) selects (an event pair costs ~3 us of stream time).
+        `decode` (PostProcessor.detect's side of the fused head decode): dict(pp=..., ws=..., store_heads=bool); when
+        every head launch of the plan qualifies, the head convolutions decode their own scale into ws (records,
+        candidates, counts; counts zeroed by the caller) and decode["done"] is set; the heads are returned only with
+        store_heads (None otherwise).  When not, the plain plan runs and decode["done"] stays False."""
         if not isinstance(images, torch.Tensor):
             images = torch.as_tensor(np.asarray(images), dtype=torch.float32)
         if images.dim() != 4 or images.shape[-1] != 3:
@@ -331,22 +367,40 @@ class Network(object):
         B, H, W, _ = images.shape
         step = B if not chunk else max(1, min(int(chunk), B))
         first = self.plan_for(step, H, W)
+        chunks = [(b0, min(step, B - b0)) for b0 in range(0, B, step)]
+        plans = {nb: (first if nb == step else self.plan_for(nb, H, W)) for _, nb in chunks}
+        fused = None
+        if decode is not None:
+            decode["done"] = False
+            fused = {nb: cp.decode_launchers(decode["pp"]) for nb, cp in plans.items()}
+            if any(v[1] is None for v in fused.values()):
+                fused = None
+        want_heads = fused is None or decode["store_heads"]
         heads = [torch.empty((B, hd["h"], hd["w"], hd["ld"]), dtype=torch.float32, device=self.device)
-                 for hd in first.plan.heads]
+                 for hd in first.plan.heads] if want_heads else None
         stream = torch.cuda.current_stream(self.device).cuda_stream
         in_base = images.data_ptr()
-        for b0 in range(0, B, step):
-            nb = min(step, B - b0)
-            cp = first if nb == step else self.plan_for(nb, H, W)
+        for b0, nb in chunks:
+            cp = plans[nb]
             env = {"in": in_base + b0 * H * W * 3 * 4, "stream": stream,
-                   "heads": [h.data_ptr() + b0 * h.stride(0) * 4 for h in heads]}
+                   "heads": [h.data_ptr() + b0 * h.stride(0) * 4 for h in heads] if want_heads else [0] * len(first.plan.heads)}
+            launchers = cp.launchers
+            if fused is not None:
+                ws, N, C = decode["ws"], fused[nb][0].boxes_per_image, fused[nb][0].num_classes
+                env["decode"] = dict(store_heads=bool(decode["store_heads"]),
+                                     letterbox=ws["letterbox"].data_ptr() + b0 * 16,
+                                     records=ws["records"].data_ptr() + b0 * N * 32,
+                                     cand_idx=ws["cand_idx"].data_ptr() + b0 * N * 4,
+                                     cand_count=ws["counts"].data_ptr() + b0 * 4,
+                                     class_count=ws["counts"].data_ptr() + (B + b0 * C) * 4)
+                launchers = fused[nb][1]
             if trace is None:
-                for launch in cp.launchers:
+                for launch in launchers:
                     rc = launch(env)
                     if rc:
                         _lib.check(rc)
             else:
-                for op, launch in zip(cp.plan.ops, cp.launchers):
+                for op, launch in zip(cp.plan.ops, launchers):
                     if trace_filter is not None and not trace_filter(op):
                         rc = launch(env)
                         if rc:
@@ -361,6 +415,10 @@ class Network(object):
                         _lib.check(rc)
                     trace.append((op, e0, e1))
         self._keepalive = images
+        if fused is not None:
+            decode["done"] = True
+        if not want_heads:
+            return None
         return [h[..., :hd["c"]] for h, hd in zip(heads, first.plan.heads)]
 
     __call__ = forward

@@ -36,6 +36,7 @@
 // Compile-time switches, default off because they measured slower: Y3_XPF (cross-tile prefetch),
 // Y3_STORE_AUX / Y3_RES_AUX (cache policy of the epilogue's stores and residual loads).
 #include "common.h"
+#include "decode_box.h"
 #include <type_traits>
 
 namespace {
@@ -95,11 +96,21 @@ __device__ __forceinline__ void row_setup(const ConvArgs &p, int gm, int es, lon
 
 constexpr int CONV_NO_BIAS = 1 << 24;    // internal flag: split-K partial sums carry no bias
 
+// Head decode fused into a head convolution's epilogue (y3_conv2d_head_decode): what y3_decode needs for ONE scale.
+struct HeadDecode {
+    const float *letterbox;              // [B][4]: scale, off_h, off_w (utils/utils.py:100-116)
+    float *records;                      // [B][N][8]
+    int *cand_idx, *cand_count, *class_count;
+    int N, C, scale_base, store_heads;   // boxes per image (all scales), classes, first box index of this scale
+    float stride_x, stride_y, thr;
+    float anchor[3][2];
+};
+
 // Epilogue shared by the convolution kernels: accumulators -> LDS (fp32) -> bias, leaky, residual ->
 // NHWC rows with 16-byte stores, EP_ROWS tile rows per pass.
-template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, int MI, int NI>
+template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, int MI, int NI, bool DECODE = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI][MI], char *smem, int m0, int n0,
-                                              int tid, int wm, int wn, long out_shift = 0) {
+                                              int tid, int wm, int wn, long out_shift = 0, const HeadDecode *hd = nullptr) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int ES = BF16 ? 2 : 4;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
@@ -138,19 +149,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int n = wn * TN + ni * 16 + fq * 4;
-                *(f32x4 *)(Cs + (rb + frow) * CS_LD + n) = acc[ni][mi];
+                f32x4 v = acc[ni][mi];
+                if constexpr (DECODE) v += *(const f32x4 *)(p.bias + n0 + n);      // the decode below reads finished head values
+                *(f32x4 *)(Cs + (rb + frow) * CS_LD + n) = v;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < O_IT; ++i) {
+            if constexpr (DECODE) {
+                if (!hd->store_heads) break;         // the caller did not ask for the head tensor itself
+            }
             const int q = tid + NT * i;
             const int row = q / NCH, ch = q % NCH;
             const int gm = m0 + pass * EP_ROWS + row, n = n0 + ch * 8;
             if (gm >= p.M || n >= p.Cout8) continue;
             f32x4 v0 = *(const f32x4 *)(Cs + row * CS_LD + ch * 8);
             f32x4 v1 = *(const f32x4 *)(Cs + row * CS_LD + ch * 8 + 4);
-            if (!(p.flags & CONV_NO_BIAS)) {         // split-K partial sums: the bias is added once, by the finishing kernel
+            if (!DECODE && !(p.flags & CONV_NO_BIAS)) {         // split-K partial sums: the bias is added once, by the finishing kernel
                 v0 += *(const f32x4 *)(p.bias + n);
                 v1 += *(const f32x4 *)(p.bias + n + 4);
             }
@@ -200,6 +216,59 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
                     o[3] = pack_bf16x2(v1[2], v1[3]);
                     *(u32x4 *)(p.out + (pix * p.out_ld + n) * 2) = o;
                 }
+            }
+        }
+        if constexpr (DECODE) {
+            // ---- head decode of this pass's EP_ROWS grid cells x 3 anchors, straight from the staged fp32 values --------
+            // (what decode_lane_kernel does after copying the head back from HBM: same per-box code, decode_box.h)
+            __shared__ int s_cnt[2], s_base[2];
+            __shared__ int s_hist[2][96];
+            __shared__ int s_list[2][EP_ROWS * 3];
+            const int C = hd->C, E = 5 + C;
+            const int row0 = m0 + pass * EP_ROWS;
+            if (row0 >= p.M) break;                                  // block-uniform
+            const int b_lo = fast_div(row0, p.fd_howo);              // a pass spans at most two images (HoWo >= EP_ROWS)
+            if (tid < 2) s_cnt[tid] = 0;
+            if (tid < 2 * 96) (&s_hist[0][0])[tid] = 0;
+            __syncthreads();                                         // the head stores above have read Cs; counters are clear
+            if ((tid & ~63) < EP_ROWS * 3) {                         // wave-uniform
+                const int row = tid / 3, an = tid - row * 3;
+                const int gm = row0 + row;
+                const bool live = tid < EP_ROWS * 3 && gm < p.M;
+                const int gmc = live ? gm : row0;
+                const int b = fast_div(gmc, p.fd_howo);
+                const int cell = gmc - b * p.HoWo;
+                const int gy = fast_div(cell, p.fd_wo), gx = cell - gy * p.Wo;
+                const float scale = hd->letterbox[b * 4 + 0], off_h = hd->letterbox[b * 4 + 1], off_w = hd->letterbox[b * 4 + 2];
+                float *tl = Cs + (live ? row : 0) * CS_LD + an * E;
+                const DecodedBox o = y3_decode_box(tl, live, C, gx, gy, hd->stride_x, hd->stride_y, hd->anchor[an][0],
+                                                   hd->anchor[an][1], scale, off_h, off_w);
+                const int pbox = hd->scale_base + cell * 3 + an;
+                if (live) {
+                    float *r = hd->records + ((long)b * hd->N + pbox) * 8;
+                    *(f32x4 *)r = f32x4{o.ymin, o.xmin, o.ymax, o.xmax};
+                    *(f32x4 *)(r + 4) = f32x4{o.score, __uint_as_float(o.m0), __uint_as_float(o.m1), __uint_as_float(o.m2)};
+                    if (o.score >= hd->thr) {                                          // inference.py:127
+                        const int slot = b - b_lo;
+                        s_list[slot][atomicAdd(&s_cnt[slot], 1)] = pbox;
+                        unsigned mm[3] = {o.m0, o.m1, o.m2};
+                        for (int w = 0; w < 3; ++w)
+                            while (mm[w]) { const int bit = __ffs(mm[w]) - 1; mm[w] &= mm[w] - 1; atomicAdd(&s_hist[slot][w * 32 + bit], 1); }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 2 && s_cnt[tid]) s_base[tid] = atomicAdd(&hd->cand_count[b_lo + tid], s_cnt[tid]);
+            if (tid < 2 * 96) {
+                const int slot = tid / 96, c = tid - slot * 96;
+                const int h = s_hist[slot][c];
+                if (c < C && h) atomicAdd(&hd->class_count[(b_lo + slot) * C + c], h);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int n = s_cnt[slot];
+                for (int i = tid; i < n; i += NT) hd->cand_idx[(long)(b_lo + slot) * hd->N + s_base[slot] + i] = s_list[slot][i];
             }
         }
     }
@@ -322,10 +391,10 @@ constexpr int conv_waves_per_simd(int lds_bytes, int waves) {
     return (wg * waves + 3) / 4;
 }
 
-template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, bool INTERLEAVE>
+template <bool BF16, int BM, int BN, int WAVES_M, int WAVES_N, int EP_ROWS, bool INTERLEAVE, bool DECODE = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
 __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(2 * (BM + BN) * 128, WAVES_M * WAVES_N), conv_waves_per_simd(2 * (BM + BN) * 128, WAVES_M * WAVES_N))))
-void conv_igemm_kernel(const ConvArgs p) {
+void conv_igemm_kernel(const ConvArgs p, const HeadDecode hd) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;   // threads
     constexpr int ES = BF16 ? 2 : 4;             // element bytes
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
@@ -570,8 +639,8 @@ void conv_igemm_kernel(const ConvArgs p) {
             continue;
         }
     }
-    conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI>(p, acc, smem, m0, n0, tid, wm, wn,
-                                                                   p.splits > 1 ? (long)(kt0 / p.nk_split) * p.slice_elems : 0L);
+    conv_epilogue<BF16, BM, BN, WAVES_M, WAVES_N, EP_ROWS, MI, NI, DECODE>(p, acc, smem, m0, n0, tid, wm, wn,
+                                                                           p.splits > 1 ? (long)(kt0 / p.nk_split) * p.slice_elems : 0L, &hd);
     __syncthreads();                             // the LDS epilogue's staging area overlaps the pipeline buffers
     }
 }
@@ -885,13 +954,13 @@ void conv_direct_pool_kernel(const DirectArgs p) {
     }
 }
 
-template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS, bool IL>
-int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
+template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS, bool IL, bool DEC = false>
+int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream, const HeadDecode *hd = nullptr) {
     constexpr int stage_bytes = 2 * (BM + BN) * 128;
     constexpr int cs_bytes = EP_ROWS * (BN + 4) * 4;
     constexpr int lds = stage_bytes > cs_bytes ? stage_bytes : cs_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv_igemm_kernel<BF16, BM, BN, WM, WN, EP_ROWS, IL>;
+    auto kern = conv_igemm_kernel<BF16, BM, BN, WM, WN, EP_ROWS, IL, DEC>;
     a.n_tiles = n_pad / BN;
     static thread_local int attr_dev = -1;
     int dev = 0;
@@ -923,7 +992,7 @@ int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream) {
         a.delay_ticks = (unsigned)(tile_us * g_conv_phase_pct);                              // 100 ticks per us, percent
         a.delay_from = (int)rem;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, stream, a, hd ? *hd : HeadDecode{});
     return y3_check_launch("conv_igemm");
 }
 
@@ -958,7 +1027,11 @@ int launch_ring(ConvArgs a, int n_pad, hipStream_t stream) {
 }
 
 template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS>
-int launch_igemm(const ConvArgs &a, int n_pad, hipStream_t stream) {
+int launch_igemm(const ConvArgs &a, int n_pad, hipStream_t stream, const HeadDecode *hd = nullptr) {
+    if constexpr (BF16 && BN == 256 && BM >= 192) {      // the tiles that hold all 255 head channels of their pixels
+        if (hd) return launch_igemm_<BF16, BM, BN, WM, WN, EP_ROWS, true, true>(a, n_pad, stream, hd);
+    }
+    if (hd) { y3_set_error("conv: this tile has no fused head decode"); return Y3_E_INVALID; }
     if (g_conv_debug & 2) return launch_igemm_<BF16, BM, BN, WM, WN, EP_ROWS, false>(a, n_pad, stream);
     return launch_igemm_<BF16, BM, BN, WM, WN, EP_ROWS, true>(a, n_pad, stream);
 }
@@ -1029,7 +1102,8 @@ extern "C" int y3_conv_weight_layout(y3_conv_desc *d) {
 // splits > 1: the launch writes `splits` fp32 partial sums per output to `workspace` (no bias, activation,
 // shortcut or upsampling: conv_splitk_finish_kernel applies those once).
 static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, const float *bias,
-                       const void *residual, void *out, const void *zeros, hipStream_t stream, float *workspace, int splits) {
+                       const void *residual, void *out, const void *zeros, hipStream_t stream, float *workspace, int splits,
+                       const HeadDecode *hd = nullptr) {
     Y3_REQUIRE(d && in && w && bias && out && zeros, Y3_E_INVALID, "conv: null pointer argument");
     y3_conv_desc chk = *d;
     const int family = y3_conv_weight_layout(&chk);
@@ -1141,6 +1215,11 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
             a.res_bytes = (unsigned)rb;
         }
     }
+    if (hd) {                                      // fused head decode: only the two tiles that carry it
+        Y3_REQUIRE(bf16 && !(a.flags & CONV_REG_EPILOGUE) && d->n_pad == 256, Y3_E_INVALID, "conv_head_decode: not a bf16 -> fp32 head launch");
+        if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream, hd);
+        return launch_igemm<true, 192, 256, 2, 4, 96>(a, d->n_pad, stream, hd);
+    }
     const bool ring = g_conv_debug & 4;            // ring-pipelined kernels (experiment switch)
     if (ring && v == 192) v = 256;
     if (ring && (v == 256 || v == 128)) {
@@ -1174,6 +1253,60 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
 extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void *w, const float *bias,
                                const void *residual, void *out, const void *zeros, void *stream) {
     return conv_launch(d, in, w, bias, residual, out, zeros, (hipStream_t)stream, nullptr, 1);
+}
+
+// ---- a head convolution with the YOLO decode of its scale in the epilogue -----------------------------------------
+// The three head convolutions (1x1 -> 3 * (5 + C) channels, linear, fp32 out) are the producers of everything
+// y3_decode reads; un-fused, the fp32 heads (497 MB at 608, batch 64) are written and read straight back.  Here the
+// tile's finished fp32 values are decoded where they are staged for the store (LDS), with decode_lane_kernel's own
+// per-box code (decode_box.h: identical records), and the head tensor itself is written only if the caller wants it.
+namespace {
+bool head_decode_ok(const y3_conv_desc *d, const y3_decode_desc *dd, int scale, const char **why) {
+    *why = nullptr;
+    if (d->dtype != Y3_BF16 || !(d->flags & Y3_CONV_OUT_F32)) *why = "bf16 convolution with fp32 output required";
+    else if (d->flags & (Y3_CONV_LEAKY | Y3_CONV_RESIDUAL | Y3_CONV_UPS2X | Y3_CONV_POOL2 | Y3_CONV_IN_F32)) *why = "head convolutions are linear and plain";
+    else if (scale < 0 || scale >= dd->num_scales) *why = "scale index out of range";
+    else if (dd->num_anchors != 3 || dd->num_classes < 1 || dd->num_classes > 80 || d->out_c != 3 * (5 + dd->num_classes)) *why = "3 anchors x (5 + classes <= 80) output channels required";
+    else if (d->n_pad != 256) *why = "one 256-channel tile must hold all head channels";
+    else if (dd->grid_h[scale] != d->out_h || dd->grid_w[scale] != d->out_w || dd->batch != d->batch) *why = "decode grid and convolution output differ";
+    else if (d->out_h * d->out_w < 128) *why = "grid smaller than an epilogue pass";
+    if (*why) return false;
+    // the decode lives in the 256- and 192-pixel tiles; a launch the heuristic would give 128-pixel tiles runs on the
+    // 192-pixel one instead (same sums, same bits), which only pays when it still fills a good part of the chip
+    if ((long)d->batch * d->out_h * d->out_w < 8192) { *why = "launch too small for the 256 / 192-pixel tiles"; return false; }
+    return true;
+}
+}  // namespace
+
+extern "C" int y3_conv_head_decode_ok(const y3_conv_desc *d, const y3_decode_desc *dd, int scale) {
+    if (!d || !dd) return 0;
+    y3_conv_desc chk = *d;
+    if (y3_conv_weight_layout(&chk) != 0 || chk.n_pad != d->n_pad || chk.k_pad != d->k_pad) return 0;
+    const char *why;
+    return head_decode_ok(d, dd, scale, &why) ? 1 : 0;
+}
+
+extern "C" int y3_conv2d_head_decode(const y3_conv_desc *d, const void *in, const void *w, const float *bias, void *out,
+                                     const void *zeros, const y3_decode_desc *dd, int scale, const float *letterbox,
+                                     float *records, int32_t *cand_idx, int32_t *cand_count, int32_t *class_count, void *stream) {
+    Y3_REQUIRE(d && dd && letterbox && records && cand_idx && cand_count && class_count && zeros, Y3_E_INVALID, "conv_head_decode: null pointer");
+    const char *why;
+    Y3_REQUIRE(head_decode_ok(d, dd, scale, &why), Y3_E_INVALID, "conv_head_decode: %s", why);
+    Y3_REQUIRE(aligned16(records), Y3_E_ALIGN, "conv_head_decode: records not 16-byte aligned");
+    HeadDecode h;
+    h.letterbox = letterbox; h.records = records; h.cand_idx = cand_idx; h.cand_count = cand_count; h.class_count = class_count;
+    h.C = dd->num_classes;
+    int base = 0, total = 0;
+    for (int l = 0; l < dd->num_scales; ++l) {
+        if (l == scale) base = total;
+        total += dd->grid_h[l] * dd->grid_w[l] * dd->num_anchors;
+    }
+    Y3_REQUIRE(total == dd->boxes_per_image, Y3_E_INVALID, "conv_head_decode: boxes_per_image %d, grids give %d", dd->boxes_per_image, total);
+    h.N = total; h.scale_base = base; h.store_heads = out != nullptr;
+    h.stride_x = dd->stride_x[scale]; h.stride_y = dd->stride_y[scale]; h.thr = dd->score_threshold;
+    for (int a = 0; a < 3; ++a) { h.anchor[a][0] = dd->anchors[scale][a][0]; h.anchor[a][1] = dd->anchors[scale][a][1]; }
+    // (without a head tensor the kernel stores nothing through `out`; the zero page only satisfies the launcher's checks)
+    return conv_launch(d, in, w, bias, nullptr, out ? out : (void *)zeros, zeros, (hipStream_t)stream, nullptr, 1, &h);
 }
 
 // ---- split-K: small launches (few output tiles, long k) --------------------------------------------------------

@@ -9,6 +9,7 @@
 // fp32 throughout, no multiply-add contraction (the file is built with
 // -ffp-contract=off), IEEE division, operation order as in the reference.
 #include "common.h"
+#include "decode_box.h"
 
 namespace {
 
@@ -247,88 +248,12 @@ __global__ __launch_bounds__(kThreads) void decode_lane_kernel(const DecodeArgs2
 
         const int cell = cell0 + ci;
         const bool live = has_box && cell < ncell;
-        const float *tl = (const float *)(my + (live ? ci : 0) * kCellPitch) + an * E;
-        // (unrolled by 16: the LDS reads of a batch are in flight together instead of one round trip per class)
-        float tmax = -__builtin_inff();
-        {
-            int c = 0;
-            for (; c + 16 <= C; c += 16) {
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = tl[5 + c + u];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) tmax = vmax_raw(tmax, v[u]);
-            }
-            for (; c < C; ++c) tmax = fmaxf(tmax, tl[5 + c]);
-        }
-        // sigmoid is increasing, so only logits close enough to the largest one that their fp32 sigmoid could
-        // still reach the maximum need the exact evaluation: a logit more than `win` below tmax has a true
-        // sigmoid at least 8 ulp below sigmoid(tmax) (win * sigmoid'(tmax) = 1e-6 * sigmoid(tmax)); the fp32
-        // evaluation errs by 2-3.  Where sigmoid underflows (tmax < -80) every class is evaluated.
-        const float win = tmax < -80.0f ? __builtin_inff() : 1e-6f * (1.0f + __expf(tmax)) + 1e-6f * fabsf(tmax);
-        const float tcut = tmax - win;
-        unsigned need[3] = {0u, 0u, 0u};
-        {
-            int c = 0;
-            for (; c + 16 <= C; c += 16) {               // 16 never straddles a 32-bit mask word
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = tl[5 + c + u];
-                unsigned bits = 0;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) bits |= (v[u] >= tcut ? 1u : 0u) << u;
-                const unsigned sh = bits << (c & 31);
-                if ((c >> 5) == 0) need[0] |= sh; else if ((c >> 5) == 1) need[1] |= sh; else need[2] |= sh;
-            }
-            for (; c < C; ++c) {
-                const unsigned bit = (tl[5 + c] >= tcut ? 1u : 0u) << (c & 31);
-                if ((c >> 5) == 0) need[0] |= bit; else if ((c >> 5) == 1) need[1] |= bit; else need[2] |= bit;
-            }
-        }
-        if (!live) need[0] = need[1] = need[2] = 0u;
-        // exact sigmoid of the needed classes (usually one per box), written back over the logit
-        float pmax = -1.0f;
-        unsigned todo[3] = {need[0], need[1], need[2]};
-        float *tw = (float *)(my + (live ? ci : 0) * kCellPitch) + an * E;
-        while (__builtin_amdgcn_ballot_w64((todo[0] | todo[1] | todo[2]) != 0u)) {
-            const int w = todo[0] ? 0 : (todo[1] ? 1 : 2);
-            const unsigned m = w == 0 ? todo[0] : (w == 1 ? todo[1] : todo[2]);
-            if (m) {
-                const int c = w * 32 + __ffs(m) - 1;
-                const float pv = sigmoidf_(tw[5 + c]);                                  // utils.py:87
-                tw[5 + c] = pv;
-                pmax = fmaxf(pmax, pv);                                                // utils.py:150
-                if (w == 0) todo[0] = m & (m - 1); else if (w == 1) todo[1] = m & (m - 1); else todo[2] = m & (m - 1);
-            }
-        }
-        unsigned m0 = 0, m1 = 0, m2 = 0;
-        todo[0] = need[0]; todo[1] = need[1]; todo[2] = need[2];
-        while (__builtin_amdgcn_ballot_w64((todo[0] | todo[1] | todo[2]) != 0u)) {
-            const int w = todo[0] ? 0 : (todo[1] ? 1 : 2);
-            const unsigned m = w == 0 ? todo[0] : (w == 1 ? todo[1] : todo[2]);
-            if (m) {
-                const int bit = __ffs(m) - 1;
-                if (tw[5 + w * 32 + bit] >= pmax) {                                    // utils.py:151
-                    if (w == 0) m0 |= 1u << bit; else if (w == 1) m1 |= 1u << bit; else m2 |= 1u << bit;
-                }
-                if (w == 0) todo[0] = m & (m - 1); else if (w == 1) todo[1] = m & (m - 1); else todo[2] = m & (m - 1);
-            }
-        }
-
-        // utils.py:84-92
+        float *tl = (float *)(my + (live ? ci : 0) * kCellPitch) + an * E;
         const int gy = cell / gw, gx = cell - gy * gw;
-        const float bx = (sigmoidf_(tl[0]) + (float)gx) * a.d.stride_x[l];
-        const float by = (sigmoidf_(tl[1]) + (float)gy) * a.d.stride_y[l];
-        const float bw = expf(tl[2]) * a.d.anchors[l][an < 3 ? an : 0][0];
-        const float bh = expf(tl[3]) * a.d.anchors[l][an < 3 ? an : 0][1];
-        const float conf = sigmoidf_(tl[4]);
-        // utils.py:118-126
-        const float hw = bw / 2.0f, hh = bh / 2.0f;
-        const float ymin = ((by - hh) - off_h / 2.0f) / scale;
-        const float xmin = ((bx - hw) - off_w / 2.0f) / scale;
-        const float ymax = ((by + hh) - off_h / 2.0f) / scale;
-        const float xmax = ((bx + hw) - off_w / 2.0f) / scale;
-        const float score = conf * (pmax * 1.0f);                                      // utils.py:153-154
+        const DecodedBox o = y3_decode_box(tl, live, C, gx, gy, a.d.stride_x[l], a.d.stride_y[l], a.d.anchors[l][an < 3 ? an : 0][0],
+                                           a.d.anchors[l][an < 3 ? an : 0][1], scale, off_h, off_w);
+        const float ymin = o.ymin, xmin = o.xmin, ymax = o.ymax, xmax = o.xmax, score = o.score;
+        const unsigned m0 = o.m0, m1 = o.m1, m2 = o.m2;
 
         const int p = a.scale_base[l] + cell * A + an;
         if (live) {

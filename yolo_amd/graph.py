@@ -26,9 +26,9 @@ class GraphedDetector(object):
         self._ws = None
 
     def _eager(self, image_shapes):
-        heads = self.net.forward(self.images)
-        args = self.pp.prepare(heads, image_shapes)
-        return heads, args, self.pp.launch(*args)
+        # backbone -> decode -> NMS -> pack; the decode runs inside the head convolutions where the plan allows
+        # (postprocess.PostProcessor.detect); the head tensors are kept (self.heads) as before
+        return self.pp.detect(self.net, self.images, image_shapes, want_heads=True)
 
     def capture(self, image_shapes=None):
         """Warm up on a side stream (first launches set kernel attributes and allocate the workspace, neither
@@ -43,10 +43,9 @@ class GraphedDetector(object):
         torch.cuda.synchronize(self.net.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            heads = self.net.forward(self.images)
-            args = self.pp.prepare(heads, shapes)      # workspace exists, shapes unchanged: no allocation, no copy
-            det = self.pp.launch(*args)
-        self.graph, self.heads, self.det, self._ws = graph, heads, det, args[2]
+            det, heads = self._eager(shapes)           # workspace exists, shapes unchanged: no allocation, no copy
+        ws = self.pp._workspace(self.batch, int(det.records.shape[1]), self.net.device)
+        self.graph, self.heads, self.det, self._ws = graph, heads, det, ws
         return self
 
     def __call__(self, image_shapes=None):

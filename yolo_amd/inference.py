@@ -93,6 +93,18 @@ def predict_batch(output_nodes, anchors, num_classes, input_shape, image_shape):
     return _postprocessor(anchors, num_classes, input_shape)(list(output_nodes), image_shape)
 
 
+def detect_batch(output_nodes, images, anchors, num_classes, input_shape, image_shape, chunk=None, want_heads=False):
+    """Images -> detections in one go: what the reference's `sess.run(predict(output_nodes, ...), {input: images})`
+    evaluates (inference.py:88-167, 277).  output_nodes: what `yolo()` returned (or a build_model.Network).  The decode
+    of each scale runs inside its head convolution where the plan allows it, so the fp32 heads are not read back (nor
+    written, unless want_heads); otherwise this is `predict_batch(output_nodes(images), ...)`.  Same results either way.
+    Returns postprocess.Detections, or (Detections, heads) with want_heads."""
+    net = getattr(output_nodes, "net", output_nodes)
+    det, heads = _postprocessor(anchors, num_classes, input_shape).detect(net, images, image_shape, chunk=chunk,
+                                                                          want_heads=want_heads)
+    return (det, heads) if want_heads else det
+
+
 def predict(output_nodes, anchors, num_classes, input_shape, image_shape):
     """Reference contract (inference.py:88-167): boxes [M,4] (y_min,x_min,y_max,x_max) fp32,
     scores [M] fp32, classes [M] int32; class-major, within a class in NMS selection order.
@@ -239,10 +251,10 @@ def run_inference(img_path, output_dir, args):
             triples = [graphed.image(j) for j in range(n)]
         else:
             tick = time()
-            heads = output_nodes(staged[:n])
-            det = predict(heads, anchors, num_classes, input_shape, hws[0] if n == 1 else np.asarray(hws))
-            det = [det] if n == 1 else det
-            triples = [tuple(t.cpu().numpy() for t in d) for d in det]
+            det = detect_batch(output_nodes, staged[:n], anchors, num_classes, input_shape, np.asarray(hws))
+            counts = det.count.cpu().numpy()
+            triples = [(det.boxes[j, :m].cpu().numpy(), det.scores[j, :m].cpu().numpy(), det.classes[j, :m].cpu().numpy())
+                       for j, m in enumerate(counts)]
         tock = time()
         total_time_pred.append((tock - tick, n))
         for j, (image, (out_boxes, out_scores, out_classes)) in enumerate(zip(chunk, triples)):

@@ -86,14 +86,9 @@ class PostProcessor(object):
             self._ws[key] = ws
         return ws
 
-    def prepare(self, heads, image_shapes):
-        """Host side of a call: validates the head tensors, builds the decode descriptor, makes sure the
-        workspace exists and uploads the per-image letterbox scalars when the image shapes changed.  Nothing
-        here may run under HIP graph capture (allocation, host -> device copy); `launch` is what a graph holds."""
-        views = [_head_view(h) for h in heads]
-        B = views[0][0].shape[0]
-        device = views[0][0].device
-        L = len(views)
+    def describe(self, B, grids):
+        """y3_decode_desc for a batch of B images and head grids [(gh, gw, ld), ...] (coarse first)."""
+        L = len(grids)
         masks = anchor_masks(L)
         C = self.num_classes
         d = _lib.DecodeDesc()
@@ -101,10 +96,7 @@ class PostProcessor(object):
         A = len(masks[0])
         d.num_anchors = A
         N = 0
-        for l, (t, ld) in enumerate(views):
-            gh, gw = t.shape[1], t.shape[2]
-            if t.shape[3] != A * (5 + C):
-                raise ValueError("head %d has %d channels, expected %d" % (l, t.shape[3], A * (5 + C)))
+        for l, (gh, gw, ld) in enumerate(grids):
             d.grid_h[l], d.grid_w[l], d.head_ld[l] = gh, gw, ld
             for a, ai in enumerate(masks[l]):
                 d.anchors[l][a][0] = float(self.anchors[ai][0])
@@ -115,6 +107,44 @@ class PostProcessor(object):
             N += gh * gw * A
         d.score_threshold = self.score_threshold
         d.boxes_per_image = N
+        return d
+
+    def detect(self, net, images, image_shapes, chunk=None, want_heads=False, trace=None, trace_filter=None):
+        """The whole step on a build_model.Network: backbone -> decode -> NMS -> pack, with the decode of each scale
+        fused into its head convolution's epilogue where the plan allows (bf16, launches on the 256 / 192-pixel tiles:
+        the fp32 heads are then never read back, and not even written unless want_heads), else backbone + y3_decode.
+        Same records, same detections either way (tests/test_gpu_e2e.py).  Returns (Detections, heads or None)."""
+        images = images if isinstance(images, torch.Tensor) else torch.as_tensor(np.asarray(images), dtype=torch.float32)
+        B, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+        step = B if not chunk else max(1, min(int(chunk), B))
+        hds = net.plan_for(step, H, W).plan.heads
+        grids = [(h["h"], h["w"], h["ld"]) for h in hds]
+        d = self.describe(B, grids)
+        N, L = d.boxes_per_image, len(grids)
+        ws = self._workspace(B, N, net.device)
+        self.set_image_shapes(ws, B, image_shapes)
+        ws["counts"].zero_()
+        dec = dict(pp=self, ws=ws, store_heads=bool(want_heads))
+        heads = net.forward(images, chunk=chunk, trace=trace, trace_filter=trace_filter, decode=dec)
+        if dec["done"]:
+            return self._finish(d, ws, (B, N, L), net.device), heads
+        views = [_head_view(h) for h in heads]
+        return self.launch(views, d, ws, (B, N, L)), heads
+
+    def prepare(self, heads, image_shapes):
+        """Host side of a call: validates the head tensors, builds the decode descriptor, makes sure the
+        workspace exists and uploads the per-image letterbox scalars when the image shapes changed.  Nothing
+        here may run under HIP graph capture (allocation, host -> device copy); `launch` is what a graph holds."""
+        views = [_head_view(h) for h in heads]
+        B = views[0][0].shape[0]
+        device = views[0][0].device
+        L = len(views)
+        A = len(anchor_masks(L)[0])
+        for l, (t, ld) in enumerate(views):
+            if t.shape[3] != A * (5 + self.num_classes):
+                raise ValueError("head %d has %d channels, expected %d" % (l, t.shape[3], A * (5 + self.num_classes)))
+        d = self.describe(B, [(t.shape[1], t.shape[2], ld) for t, ld in views])
+        N = d.boxes_per_image
         ws = self._workspace(B, N, device)
         self.set_image_shapes(ws, B, image_shapes)
         return views, d, ws, (B, N, L)
@@ -147,6 +177,17 @@ class PostProcessor(object):
         _lib.check(lib.y3_decode(ctypes.byref(d), hp[0], hp[1], hp[2], ws["letterbox"].data_ptr(),
                                  ws["records"].data_ptr(), ws["cand_idx"].data_ptr(), cand_count.data_ptr(),
                                  class_count.data_ptr(), stream))
+        self._keep = views
+        return self._finish(d, ws, dims, device)
+
+    def _finish(self, d, ws, dims, device):
+        """NMS + pack on the decoded records of ws (from y3_decode or from the head convolutions' fused decode)."""
+        lib = _lib.load()
+        B, N, L = dims
+        C = self.num_classes
+        stream = torch.cuda.current_stream(device).cuda_stream
+        cand_count = ws["counts"][:B]
+        class_count = ws["counts"][B:]
         rank_ptr = ws["kept_rank"].data_ptr() if self.with_rank else None
         _lib.check(lib.y3_nms_bucketed(ws["records"].data_ptr(), ws["cand_idx"].data_ptr(), cand_count.data_ptr(),
                                        class_count.data_ptr(), B, N, C, self.max_boxes, self.iou_threshold,
@@ -155,7 +196,6 @@ class PostProcessor(object):
         _lib.check(lib.y3_pack_outputs(ws["records"].data_ptr(), ws["kept_idx"].data_ptr(), ws["kept_count"].data_ptr(),
                                        B, N, C, self.max_boxes, ws["out_boxes"].data_ptr(), ws["out_scores"].data_ptr(),
                                        ws["out_classes"].data_ptr(), ws["out_count"].data_ptr(), stream))
-        self._keep = views
         return Detections(ws["out_boxes"], ws["out_scores"], ws["out_classes"], ws["out_count"], ws["kept_idx"],
                           ws["kept_count"], ws["kept_rank"], ws["records"], cand_count)
 
