@@ -258,10 +258,11 @@ def main():
                                "timed_steps_with_events": len(traces)}
             try:            # HBM bytes per launch of that kernel, from the committed PMC passes (profiles/)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                for name, byt in tj["hbm_bytes_per_launch"].items():
+                for name, byt in tj["hbm_bytes_per_launch"].items():      # listed by total time: the first match is the main variant
                     if name.startswith(dom):
                         out["roofline"]["traffic"] = byt
                         out["roofline"]["traffic_source"] = tj["source"]
+                        break
             except (OSError, ValueError, KeyError):
                 pass
             w_conv = sum(e0.elapsed_time(e1) for op, e0, e1 in warm_trace if op["kind"] in ("conv", "stem", "resblock"))

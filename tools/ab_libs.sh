@@ -8,6 +8,6 @@ for r in $(seq 1 $rounds); do
   for v in "$@"; do
     if [ "$v" = main ]; then unset YOLO3HIP_LIB; else export YOLO3HIP_LIB=$PWD/gpurun_ab/libyolo3hip_$v.so; fi
     timeout -k 10 120 python tools/layer_report.py --reps 7 > gpurun_out/ab_${v}_$r.txt 2>&1
-    echo $v $r $(tail -1 gpurun_out/ab_${v}_$r.txt)
+    echo $v $r $(tail -n 1 gpurun_out/ab_${v}_$r.txt)
   done
 done
