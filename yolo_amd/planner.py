@@ -363,7 +363,7 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
             src = L["src"]
             if src < 0 or src in claimed or src in head_of or i in claimed or i in head_of or shapes[src] != shapes[i]:
                 continue
-            if layers[src]["type"] == "route" or (stem_layers is not None and src in stem_layers):
+            if layers[src]["type"] == "route":
                 continue
             if src in absorbed or src in rb_internal or inputs[p] == [src]:
                 continue
