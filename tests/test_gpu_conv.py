@@ -2,6 +2,8 @@
 C-ABI.  fp32 mode: <= 1e-3 max-abs (north_star's head-tensor tolerance, applied per layer);
 bf16 mode: inputs/weights are rounded to bf16 first so that only accumulation order and the
 final bf16 rounding differ: |err| <= 1e-2 * max(1, |ref|)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -267,6 +269,37 @@ def test_conv_cout64_tile_variants_agree():
     np.testing.assert_array_equal(outs[0], outs[64])
     np.testing.assert_array_equal(outs[0], outs[261])
     np.testing.assert_array_equal(outs[0], gpu_util.run_conv(x, k, b, 1, "bf16", leaky=True, residual=r))    # product library
+
+
+@pytest.mark.parametrize("H,W,res,leaky,pads", [(304, 304, True, True, ((0, 0), (0, 0))), (300, 304, False, True, ((32, 8), (64, 16))),
+                                                 (310, 288, True, False, ((0, 0), (0, 0)))])
+def test_conv3x3_c32_kernel_equals_the_implicit_gemm(H, W, res, leaky, pads):
+    """3x3 32 -> 64 on a large map (Darknet-53 layer 3) runs on conv3x3_c32_kernel (weights in registers, 18 x 18 input
+    patch resident in LDS): y3_conv2d_fused picks it by shape.  Against the oracle, and bit for bit against the
+    implicit-GEMM tiles it replaces (same MFMA chain per output): heights that are not tile multiples, channel slices
+    of wider buffers, with and without shortcut / leaky."""
+    from yolo_amd import _lib
+    B, C, O = 3, 32, 64
+    rng = np.random.default_rng(H + W)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, W, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((3, 3, C, O)) * np.sqrt(2.0 / (9 * C))).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    r = gpu_util.bf16_round(rng.standard_normal((B, H, W, O)).astype(np.float32)) if res else None
+    want = _ref(x, k, b, 1, leaky, residual=r)
+    kw = dict(leaky=leaky, residual=r, in_pad=pads[0], out_pad=pads[1])
+    got = gpu_util.run_conv(x, k, b, 1, "bf16", **kw)
+    assert np.all(np.abs(got - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = _lib.Y3_BF16, B, H, W, C, 32
+    d.out_h, d.out_w, d.out_c, d.out_ld, d.res_ld, d.ksize, d.stride, d.k_pad, d.n_pad = H, W, O, 64, 64, 3, 1, 320, 64
+    name = ctypes.create_string_buffer(96)
+    _lib.check(lib.y3_conv_kernel_name(ctypes.byref(d), name, 96))
+    assert name.value.decode() == "conv3x3_c32_kernel"
+    with _lib.experimental() as exp:
+        for tile in (260, 64):
+            _lib.check(exp.y3_set_conv_tile(tile))
+            np.testing.assert_array_equal(gpu_util.run_conv(x, k, b, 1, "bf16", **kw), got)
 
 
 @pytest.mark.parametrize("case", ["ring_ups", "ring_1x1_res", "head_f32_256tile"])

@@ -78,6 +78,11 @@ static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0;
 // Sizes the persistent grids, the de-phasing condition and the wave-quantisation model of the convolution launchers.
 int y3_device_cus();
 
+// conv_c32.hip: the 3x3 32 -> 64 kernel y3_conv2d_fused dispatches to by shape (same packed weights, same results)
+bool y3_conv_c32_ok(const y3_conv_desc *d, long out_bytes, long res_bytes);
+int y3_conv_c32_launch(const y3_conv_desc *d, const void *in, const void *w, const float *bias, const void *residual,
+                       void *out, const void *zeros, hipStream_t stream);
+
 // ---- shared by the convolution kernels (conv_igemm.hip, conv_resblock.hip) ------------------------------------
 struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
 

@@ -1215,6 +1215,10 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
             a.res_bytes = (unsigned)rb;
         }
     }
+    // 3x3 32 -> 64 on a large map (Darknet-53 layer 3): weights in registers, input patch resident in LDS (conv_c32.hip)
+    if (!hd && splits <= 1 && g_conv_tile == 0 && g_conv_debug == 0 && (a.flags & CONV_REG_EPILOGUE) &&
+        y3_conv_c32_ok(d, M * (long)d->out_ld * 2, (d->flags & Y3_CONV_RESIDUAL) ? M * (long)d->res_ld * 2 : 0L))
+        return y3_conv_c32_launch(d, in, w, bias, residual, out, zeros, stream);
     if (hd) {                                      // fused head decode: only the two tiles that carry it
         Y3_REQUIRE(bf16 && !(a.flags & CONV_REG_EPILOGUE) && d->n_pad == 256, Y3_E_INVALID, "conv_head_decode: not a bf16 -> fp32 head launch");
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream, hd);
@@ -1449,6 +1453,11 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
         return Y3_OK;
     }
     const long M = (long)d->batch * d->out_h * d->out_w;
+    if (d->dtype == Y3_BF16 && g_conv_tile == 0 && g_conv_debug == 0 && d->out_ld > 0 &&
+        y3_conv_c32_ok(d, M * (long)d->out_ld * 2, (d->flags & Y3_CONV_RESIDUAL) ? M * (long)d->res_ld * 2 : 0L)) {
+        snprintf(buf, (size_t)len, "conv3x3_c32_kernel");
+        return Y3_OK;
+    }
     const int v = conv_variant(d, M);
     const char *k = (g_conv_debug & 4) && v >= 128 ? "conv_igemm_ring_kernel" : "conv_igemm_kernel";
     if (v == 257) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 128, 2, 2", t);
