@@ -81,6 +81,6 @@ def test_committed_traffic_file_names_the_bench_kernels():
     assert os.path.exists(os.path.join(root, src)), src
     names = tj["hbm_bytes_per_launch"]
     for prefix in ("conv_igemm_kernel<true, 256, 256, 2, 4", "conv_igemm_kernel<true, 192, 256, 2, 4", "conv_stem_kernel",
-                   "resblock_kernel<64, 4, 2>", "conv_igemm_ring_kernel<true, 256, 128"):
+                   "conv_igemm_ring_kernel<true, 256, 128"):
         hits = [v for k, v in names.items() if k.startswith(prefix)]      # (with and without the fused head decode)
         assert 1 <= len(hits) <= 2 and hits[0] > 0, prefix

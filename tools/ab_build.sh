@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../yolo_amd/csrc"
 mkdir -p build_ab_$name ../../gpurun_ab
-for f in api conv_igemm conv_resblock conv_stem elementwise decode nms preprocess; do
+for f in $(ls *.hip | sed "s/.hip$//"); do
   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function "$@" -c $f.hip -o build_ab_$name/$f.o &
 done
 wait

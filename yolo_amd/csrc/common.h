@@ -83,6 +83,11 @@ bool y3_conv_c32_ok(const y3_conv_desc *d, long out_bytes, long res_bytes);
 int y3_conv_c32_launch(const y3_conv_desc *d, const void *in, const void *w, const float *bias, const void *residual,
                        void *out, const void *zeros, hipStream_t stream);
 
+// conv_resblock128.hip: the 128-channel residual block (y3_resblock_fused dispatches to it)
+long y3_resblock128_tiles(int batch, int h, int w);
+int y3_resblock128_launch(const y3_resblock_desc *d, const void *x, const void *w1, const float *b1, const void *w2,
+                          const float *b2, void *out, const void *zeros, hipStream_t stream);
+
 // ---- shared by the convolution kernels (conv_igemm.hip, conv_resblock.hip) ------------------------------------
 struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
 

@@ -476,8 +476,12 @@ extern "C" int y3_resblock_tiles(const y3_resblock_desc *d, int64_t *tiles) {
     Y3_REQUIRE(d != nullptr && tiles != nullptr, Y3_E_INVALID, "resblock: null pointer argument");
     Y3_REQUIRE(d->dtype == Y3_BF16, Y3_E_INVALID, "resblock: bf16 only (dtype %d)", d->dtype);
     Y3_REQUIRE(d->c == 256 || d->c == 128, Y3_E_INVALID, "resblock: %d channels (256 or 128)", d->c);
-    Y3_REQUIRE(d->batch > 0 && d->h > 0 && d->w > 0 && d->w % RB_TW == 0, Y3_E_INVALID,
-               "resblock: %d x %d x %d (width must be a multiple of %d)", d->batch, d->h, d->w, RB_TW);
+    Y3_REQUIRE(d->batch > 0 && d->h > 0 && d->w > 0, Y3_E_INVALID, "resblock: %d x %d x %d", d->batch, d->h, d->w);
+    if (d->c == 128) {                             // conv_resblock128.hip: 8 x 16-pixel tiles, any width
+        *tiles = y3_resblock128_tiles(d->batch, d->h, d->w);
+        return Y3_OK;
+    }
+    Y3_REQUIRE(d->w % RB_TW == 0, Y3_E_INVALID, "resblock: %d x %d x %d (width must be a multiple of %d)", d->batch, d->h, d->w, RB_TW);
     int ty, base, rem;
     row_tiles(d->h, &ty, &base, &rem);
     *tiles = (int64_t)d->batch * ty * (d->w / RB_TW);
@@ -501,6 +505,7 @@ extern "C" int y3_resblock_fused(const y3_resblock_desc *d, const void *x, const
     const long xb = pixels * d->x_ld * 2, ob = pixels * d->out_ld * 2;
     Y3_REQUIRE(xb < 0xffff0000L && ob < 0xffff0000L && tiles < 0x7fffffffL, Y3_E_INVALID,
                "resblock: tensors of %ld / %ld bytes exceed a 4 GiB buffer descriptor", xb, ob);
+    if (c == 128) return y3_resblock128_launch(d, x, w1, b1, w2, b2, out, zeros, (hipStream_t)stream);
     ResArgs a;
     a.x = (const char *)x; a.w1 = (const char *)w1; a.w2 = (const char *)w2; a.zeros = (const char *)zeros;
     a.b1 = b1; a.b2 = b2; a.out = (char *)out;
@@ -514,6 +519,5 @@ extern "C" int y3_resblock_fused(const y3_resblock_desc *d, const void *x, const
     a.x_bytes = (unsigned)xb; a.out_bytes = (unsigned)ob;
     a.fd_img = make_fastdiv(a.tiles_img);
     a.fd_tx = make_fastdiv(a.tiles_x);
-    if (c == 256) return launch_resblock<128, 2, 4>(a, (hipStream_t)stream);
-    return launch_resblock<64, 4, 2>(a, (hipStream_t)stream);
+    return launch_resblock<128, 2, 4>(a, (hipStream_t)stream);
 }

@@ -192,8 +192,11 @@ RESBLOCK_MIN_TILES = 1024                      # fuse only where the launch fill
 RESBLOCK_AUTO_CHANNELS = (128,)
 
 
-def resblock_tiles(batch, h, w):
-    """Workgroup tiles of y3_resblock_fused on a [batch, h, w, c] tensor, or 0 when the shape is not supported."""
+def resblock_tiles(batch, h, w, c=256):
+    """Workgroup tiles of y3_resblock_fused on a [batch, h, w, c] tensor, or 0 when the shape is not supported:
+    19 x 13-pixel tiles for c = 256 (csrc/conv_resblock.hip), 16 x 8 for c = 128 (csrc/conv_resblock128.hip, any width)."""
+    if c == 128:
+        return batch * (-(-h // 8)) * (-(-w // 16))
     if w % RESBLOCK_TILE_W:
         return 0
     return batch * (-(-h // RESBLOCK_TILE_H)) * (w // RESBLOCK_TILE_W)
@@ -228,7 +231,7 @@ def find_resblocks(layers, inputs, uses, head_of, shapes, batch, dtype, mode, ch
             continue
         if uses[i1] != 1 or uses[i3] != 1 or i1 in head_of or i3 in head_of:
             continue
-        tiles = resblock_tiles(batch, shapes[src][0], shapes[src][1])
+        tiles = resblock_tiles(batch, shapes[src][0], shapes[src][1], c)
         if tiles == 0 or (mode is None and tiles < RESBLOCK_MIN_TILES):
             continue
         found[i3] = (i1, i3, isc)
@@ -432,7 +435,7 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
             h, w, c = shapes[src]
             ops.append(dict(kind="resblock", layer=i1, layers=(i1, i3, isc), x=tens[src], y=tens[isc], hw=(h, w), c=c,
                             leaky=(layers[i1]["activation"] == "leaky", layers[i3]["activation"] == "leaky"),
-                            writes_layer=isc, tiles=resblock_tiles(batch, h, w)))
+                            writes_layer=isc, tiles=resblock_tiles(batch, h, w, c)))
         elif t == "conv":
             plan.conv_layers.append(i)
             src = inputs[i][0]
