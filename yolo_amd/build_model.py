@@ -215,7 +215,7 @@ class _CompiledPlan(object):
             dref = ctypes.byref(d)
             tiles = ctypes.c_int64(0)
             _lib.check(lib.y3_resblock_tiles(dref, ctypes.byref(tiles)))
-            op["kernel"] = "resblock_kernel<128, 2, 4" if op["c"] == 256 else "resblock128_kernel"
+            op["kernel"] = {256: "resblock_kernel<128, 2, 4", 128: "resblock128_kernel", 64: "resblock64_kernel"}[op["c"]]
             assert tiles.value == op["tiles"], "planner and library disagree on the block's tiling"
             x, y = resolver(op["x"]), resolver(op["y"])
             ptrs = (w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), net._zeros.data_ptr())

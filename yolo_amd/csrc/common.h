@@ -87,6 +87,9 @@ int y3_conv_c32_launch(const y3_conv_desc *d, const void *in, const void *w, con
 long y3_resblock128_tiles(int batch, int h, int w);
 int y3_resblock128_launch(const y3_resblock_desc *d, const void *x, const void *w1, const float *b1, const void *w2,
                           const float *b2, void *out, const void *zeros, hipStream_t stream);
+long y3_resblock64_tiles(int batch, int h, int w);
+int y3_resblock64_launch(const y3_resblock_desc *d, const void *x, const void *w1, const float *b1, const void *w2,
+                         const float *b2, void *out, const void *zeros, hipStream_t stream);
 
 // ---- shared by the convolution kernels (conv_igemm.hip, conv_resblock.hip) ------------------------------------
 struct FastDiv { unsigned magic, shift; };      // q = (umulhi(n, magic) + n) >> shift, exact for n < 2^31
@@ -114,6 +117,17 @@ __device__ __forceinline__ int xcd_remap(int orig, int nblk, bool reverse = fals
     const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     const int len = q + (x < r ? 1 : 0), i = orig >> 3;
     return start + (reverse ? len - 1 - i : i);
+}
+
+// An 8-byte LDS store the compiler does not see as one.  hipcc orders every ds_write it emits after ALL outstanding
+// LDS-DMA (s_waitcnt vmcnt(0): the DMA writes LDS and may alias), which would make a kernel wait for its prefetch of
+// the NEXT tile before writing an intermediate image of this one.  The caller guarantees the regions are disjoint and
+// publishes the store itself (s_waitcnt lgkmcnt(0) + barrier).
+__device__ __forceinline__ void lds_store8_unordered(char *dst, unsigned lo, unsigned hi) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = {lo, hi};
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) char *)dst;
+    asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
 
 // One LDS-DMA instruction: 16 bytes per lane from a per-lane global address to (wave-uniform LDS base + lane * 16).

@@ -475,10 +475,14 @@ void row_tiles(int h, int *tiles_y, int *base, int *rem) {
 extern "C" int y3_resblock_tiles(const y3_resblock_desc *d, int64_t *tiles) {
     Y3_REQUIRE(d != nullptr && tiles != nullptr, Y3_E_INVALID, "resblock: null pointer argument");
     Y3_REQUIRE(d->dtype == Y3_BF16, Y3_E_INVALID, "resblock: bf16 only (dtype %d)", d->dtype);
-    Y3_REQUIRE(d->c == 256 || d->c == 128, Y3_E_INVALID, "resblock: %d channels (256 or 128)", d->c);
+    Y3_REQUIRE(d->c == 256 || d->c == 128 || d->c == 64, Y3_E_INVALID, "resblock: %d channels (256, 128 or 64)", d->c);
     Y3_REQUIRE(d->batch > 0 && d->h > 0 && d->w > 0, Y3_E_INVALID, "resblock: %d x %d x %d", d->batch, d->h, d->w);
     if (d->c == 128) {                             // conv_resblock128.hip: 8 x 16-pixel tiles, any width
         *tiles = y3_resblock128_tiles(d->batch, d->h, d->w);
+        return Y3_OK;
+    }
+    if (d->c == 64) {                              // conv_resblock64.hip: 16 x 16-pixel tiles, any width
+        *tiles = y3_resblock64_tiles(d->batch, d->h, d->w);
         return Y3_OK;
     }
     Y3_REQUIRE(d->w % RB_TW == 0, Y3_E_INVALID, "resblock: %d x %d x %d (width must be a multiple of %d)", d->batch, d->h, d->w, RB_TW);
@@ -495,9 +499,10 @@ extern "C" int y3_resblock_fused(const y3_resblock_desc *d, const void *x, const
     if (rc) return rc;
     Y3_REQUIRE(x && w1 && b1 && w2 && b2 && out && zeros, Y3_E_INVALID, "resblock: null pointer argument");
     const int c = d->c, cm = c / 2;
-    Y3_REQUIRE(d->k1_pad == c && d->n1_pad == cm && d->k2_pad == 9 * cm && d->n2_pad == c, Y3_E_INVALID,
+    const int k2 = (9 * cm + 63) / 64 * 64;        // y3_conv_weight_layout pads packed rows to whole 64-element k-steps
+    Y3_REQUIRE(d->k1_pad == c && d->n1_pad == cm && d->k2_pad == k2 && d->n2_pad == c, Y3_E_INVALID,
                "resblock: weight layout (%d,%d,%d,%d), expected (%d,%d,%d,%d)", d->k1_pad, d->n1_pad, d->k2_pad, d->n2_pad,
-               c, cm, 9 * cm, c);
+               c, cm, k2, c);
     Y3_REQUIRE(d->x_ld >= c && d->out_ld >= c, Y3_E_INVALID, "resblock: x_ld %d / out_ld %d too small", d->x_ld, d->out_ld);
     Y3_REQUIRE(aligned16(x) && aligned16(out) && aligned16(w1) && aligned16(w2) && aligned16(b1) && aligned16(b2) &&
                (d->x_ld * 2) % 16 == 0 && (d->out_ld * 2) % 16 == 0, Y3_E_ALIGN, "resblock: operands not 16-byte aligned");
@@ -506,6 +511,7 @@ extern "C" int y3_resblock_fused(const y3_resblock_desc *d, const void *x, const
     Y3_REQUIRE(xb < 0xffff0000L && ob < 0xffff0000L && tiles < 0x7fffffffL, Y3_E_INVALID,
                "resblock: tensors of %ld / %ld bytes exceed a 4 GiB buffer descriptor", xb, ob);
     if (c == 128) return y3_resblock128_launch(d, x, w1, b1, w2, b2, out, zeros, (hipStream_t)stream);
+    if (c == 64) return y3_resblock64_launch(d, x, w1, b1, w2, b2, out, zeros, (hipStream_t)stream);
     ResArgs a;
     a.x = (const char *)x; a.w1 = (const char *)w1; a.w2 = (const char *)w2; a.zeros = (const char *)zeros;
     a.b1 = b1; a.b2 = b2; a.out = (char *)out;

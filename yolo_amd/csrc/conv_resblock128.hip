@@ -30,6 +30,10 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define R1_ABLATE 0         // timing experiments (tools/ab_build.sh builds only, garbage results): 1 no phase 1, 2 no phase 2,
 #endif                      // 4 no next-patch loads, 8 no stores
 
+#ifndef R1_PHASE1_PIPE
+#define R1_PHASE1_PIPE 1
+#endif
+
 namespace {
 
 constexpr int R1_TW = 16, R1_TH = 8;               // tile: 8 rows x 16 pixels
@@ -147,6 +151,62 @@ void resblock128_kernel(const R1Args p) {
         // ---- phase 1: y = leaky(W1 x + b1) on the patch -----------------------------------------------------------
         int frv = frow;                            // (opaque per tile: keeps phase 1's per-lane addresses out of scratch,
         asm volatile("" : "+v"(frv));              // where hipcc parks them as loop invariants and reloads behind vmcnt(0))
+#if R1_PHASE1_PIPE
+        // W1's fragments of this wave's block pair once per tile (32 registers that phase 2's accumulators take over
+        // afterwards), the patch fragments of row block j + 1 requested ahead of row block j's MFMAs, and the two
+        // 16-channel chains interleaved so that no MFMA waits for the one before it
+        {
+            bf16x8 wa[2][4], xf[4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+                    wa[q][kb] = *(const bf16x8 *)(w1buf + ((nip * 2 + q) * 16 + frv) * R1_W1P + (kb * 4 + fq) * 16);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + ((wave >> 1) * 16 + frv) * R1_XP + (kb * 4 + fq) * 16);
+#pragma unroll
+            for (int j = 0; j < ((R1_ABLATE & 1) ? 0 : 3); ++j) {
+                const int pos = ((wave + 8 * j) >> 1) * 16 + frv;
+#if R1_PHASE1_PIPE > 1
+                bf16x8 xn[4];
+                if (j < 2) {
+                    const int posn = ((wave + 8 * (j + 1)) >> 1) * 16 + frv;
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) xn[kb] = *(const bf16x8 *)(xb + posn * R1_XP + (kb * 4 + fq) * 16);
+                }
+#else
+                if (j > 0) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + pos * R1_XP + (kb * 4 + fq) * 16);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 a1[2] = {bias1[0], bias1[1]};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) a1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][kb], xf[kb], a1[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;
+                const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+                const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;    // outside: the 3x3's zero padding
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x4 v = a1[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = leaky_max(v[e], slope1);
+                    const unsigned o0 = in ? pack_bf16x2(v[0], v[1]) : 0u, o1 = in ? pack_bf16x2(v[2], v[3]) : 0u;
+                    if (pos < R1_NPOS) lds_store8_unordered(ybuf + pos * R1_YP + ((nip * 2 + q) * 16 + fq * 4) * 2, o0, o1);
+                }
+#if R1_PHASE1_PIPE > 1
+                if (j < 2) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) xf[kb] = xn[kb];
+                }
+#endif
+            }
+        }
+#else
 #pragma unroll
         for (int j = 0; j < ((R1_ABLATE & 1) ? 0 : 3); ++j) {
             const int blk = (wave + 8 * j) >> 1;   // row block 0..11 of this (row block, block pair) unit
@@ -174,12 +234,11 @@ void resblock128_kernel(const R1Args p) {
                 f32x4 v = a1[q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = leaky_max(v[e], slope1);
-                uint2 o;
-                o.x = in ? pack_bf16x2(v[0], v[1]) : 0u;
-                o.y = in ? pack_bf16x2(v[2], v[3]) : 0u;
-                if (pos < R1_NPOS) *(uint2 *)(ybuf + pos * R1_YP + ((nip * 2 + q) * 16 + fq * 4) * 2) = o;
+                const unsigned o0 = in ? pack_bf16x2(v[0], v[1]) : 0u, o1 = in ? pack_bf16x2(v[2], v[3]) : 0u;
+                if (pos < R1_NPOS) lds_store8_unordered(ybuf + pos * R1_YP + ((nip * 2 + q) * 16 + fq * 4) * 2, o0, o1);
             }
         }
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // the y image is complete
         asm volatile("" ::: "memory");

@@ -189,14 +189,18 @@ RESBLOCK_MIN_TILES = 1024                      # fuse only where the launch fill
 # Block widths the automatic mode fuses.  Measured at batch 64 / 608: C = 128 @152 0.42 ms fused against
 # 0.47 ms in two launches; C = 256 @76 0.317 ms against 0.29 ms (the tile boundary of the fused kernel is bound by the
 # CU's ~15 B/clk memory ingest, which the 1x1 launch, HBM-bound chip-wide, does not pay), so 256 stays un-fused.
-RESBLOCK_AUTO_CHANNELS = (128,)
+# C = 64 @304 (csrc/conv_resblock64.hip): stem + block 0.764 ms against stem-with-1x1 + 3x3 0.814 ms.
+RESBLOCK_AUTO_CHANNELS = (128, 64)
 
 
 def resblock_tiles(batch, h, w, c=256):
     """Workgroup tiles of y3_resblock_fused on a [batch, h, w, c] tensor, or 0 when the shape is not supported:
-    19 x 13-pixel tiles for c = 256 (csrc/conv_resblock.hip), 16 x 8 for c = 128 (csrc/conv_resblock128.hip, any width)."""
+    19 x 13-pixel tiles for c = 256 (csrc/conv_resblock.hip), 16 x 8 for c = 128 (csrc/conv_resblock128.hip, any width),
+    16 x 16 for c = 64 (csrc/conv_resblock64.hip, any width)."""
     if c == 128:
         return batch * (-(-h // 8)) * (-(-w // 16))
+    if c == 64:
+        return batch * (-(-h // 16)) * (-(-w // 16))
     if w % RESBLOCK_TILE_W:
         return 0
     return batch * (-(-h // RESBLOCK_TILE_H)) * (w // RESBLOCK_TILE_W)
@@ -211,7 +215,7 @@ def find_resblocks(layers, inputs, uses, head_of, shapes, batch, dtype, mode, ch
     Returns {index of the 3x3: (i1, i3, i_shortcut)}."""
     found = {}
     if channels is None:
-        channels = RESBLOCK_AUTO_CHANNELS if mode is None else (256, 128)
+        channels = RESBLOCK_AUTO_CHANNELS if mode is None else (256, 128, 64)
     if mode is False or (mode is None and dtype != "bf16"):
         return found
     for i3, L3 in enumerate(layers):
@@ -316,6 +320,8 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
     resblocks = find_resblocks(layers, inputs, uses, head_of, shapes, batch, dtype, resblock, rb_channels) if fuse else {}
     resblocks = {i3: v for i3, v in resblocks.items() if fused_into.get(v[2]) == i3}     # the shortcut rides the 3x3
     rb_internal = {v[0] for v in resblocks.values()}      # 1x1 outputs that never leave LDS: no buffer, no launch
+    if stem_layers is not None and stem_layers[2] in rb_internal:
+        stem_layers = (stem_layers[0], stem_layers[1], None)                             # the block's launch computes the 1x1
 
     # ---- storage: aliases, concat slices, own buffers ---------------------------------------
     bufs = []            # dict(elems, es, kind)
