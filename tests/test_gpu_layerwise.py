@@ -38,7 +38,7 @@ def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch, r
     layers, oi = od.parse_layers(cfg, 80)
     params = dw.random_params(layers, seed=31)
     x = np.random.default_rng(31).random((batch, size, size, 3), dtype=np.float32)
-    net = build_model.Network(cfg, 80, dtype="bf16", resblock=resblock)     # True: the ten residual blocks as fused launches
+    net = build_model.Network(cfg, 80, dtype="bf16", resblock=resblock)     # True: the eleven residual blocks of a 608 input as fused launches
     net.set_params(params)
     cp = net.plan_for(batch, size, size)
     has_stem = cp.plan.ops[0]["kind"] == "stem"          # otherwise the 3-channel first layer runs in fp32 (direct kernel)
@@ -89,7 +89,7 @@ def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch, r
             checked += 1
     n_conv = sum(1 for L in layers if L["type"] == "conv")
     n_rb = sum(1 for op in cp.plan.ops if op["kind"] == "resblock")
-    assert (n_rb == 10) == bool(resblock)
+    assert (n_rb == 11) == bool(resblock)
     assert checked >= n_conv - 1 - n_rb              # every convolution's tensor (the stem writes two of three, a fused block one of two)
     print("%s %d b%d: %d tensors checked, %d of %d bf16 elements off by one ulp (%.2e), worst relative %.2e"
           % (cfg_name, size, batch, checked, flipped, total, flipped / max(total, 1), worst))
