@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define Y3_VERSION 102
+#define Y3_VERSION 103
 
 enum { Y3_F32 = 0, Y3_BF16 = 1 };
 
@@ -115,8 +115,12 @@ int y3_conv_stem(const y3_stem_desc *desc, const float *image, const float *w0, 
  * residual block (build_model.py:113-179 twice, then :218-227).  The c/2-channel tensor between the two convolutions
  * never leaves LDS and x is fetched once.  w1/b1 and w2/b2 are the two layers' packed weights exactly as
  * y3_conv_weight_layout / y3_conv2d_fused take them; the result is bit-identical to y3_conv2d_fused(1x1) followed by
- * y3_conv2d_fused(3x3, Y3_CONV_RESIDUAL) on the same operands.  Supported: dtype Y3_BF16, c = 256 or 128, w a multiple
- * of 19 (the 76 / 152 feature maps of a 608 input), tensors below 4 GiB.  flags: 1 = leaky-ReLU after the 1x1,
+ * y3_conv2d_fused(3x3, Y3_CONV_RESIDUAL) on the same operands.  Supported: dtype Y3_BF16, tensors below 4 GiB, and
+ * c = 256 with w a multiple of 19 (the 76 x 76 maps of a 608 input), c = 128 at any width, c = 64 at any width.
+ * c = 64 is Darknet-53's first block, whose 1x1 y3_conv_stem otherwise computes as its third convolution: there the
+ * 1x1 sums its 64 input channels in y3_conv_stem's order (bit-identical to y3_conv_stem(c2 = 32) followed by the 3x3;
+ * against y3_conv2d_fused(1x1), which adds the same products in channel order, about one output in 10^4 differs by one
+ * bf16 ulp), so a host may move that 1x1 between the two launches freely.  flags: 1 = leaky-ReLU after the 1x1,
  * 2 = after the 3x3, Y3_CONV_REVERSE = scheduling hint.  y3_resblock_tiles (host only) says whether a shape is
  * supported (Y3_OK) and how many workgroup tiles it has, so that a planner can decide when fusing pays. */
 typedef struct y3_resblock_desc {

@@ -45,7 +45,7 @@ def test_product_library_has_no_knobs():
 
 
 def test_version_and_layout(lib):
-    assert lib.y3_version() == 102
+    assert lib.y3_version() == 103
     assert _lib.conv_weight_layout(_lib.Y3_BF16, 3, 32, 3, in_f32=True) == (1, 27, 32)
     assert _lib.conv_weight_layout(_lib.Y3_BF16, 32, 64, 3) == (0, 320, 64)
     assert _lib.conv_weight_layout(_lib.Y3_BF16, 1024, 255, 1) == (0, 1024, 256)
