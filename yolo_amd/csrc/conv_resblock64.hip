@@ -31,6 +31,9 @@ constexpr int R6_XBUF = (R6_XSLOTS + R6_NT - 1) / R6_NT * R6_NT * 16;   // 57,34
 constexpr int R6_NBLK = (R6_NPOS + 15) / 16;       // 21 row blocks of 16 patch pixels in phase 1
 constexpr int R6_YBUF = R6_NPOS * R6_YP;           // 31,104
 constexpr int R6_LDS = 2 * R6_XBUF + R6_YBUF;      // 145,792
+#ifndef R6_FASTPATH
+#define R6_FASTPATH 1                              // interior tiles: loader offsets from registers, no bounds arithmetic
+#endif
 #ifndef R6_SPREAD
 #define R6_SPREAD 1                                // loader passes among phase 2's first taps (0: all at the top of the tile): -2 %
 #endif
@@ -89,8 +92,30 @@ void resblock64_kernel(const R6Args p) {
         h0 = ty * R6_T;
         w0 = (ti - ty * p.tiles_x) * R6_T;
     };
-    // the tile's 18 x 18 x 64 input patch -> LDS: slot s = 10 * pixel + chunk, chunks 8 and 9 are padding (not written)
-    auto issue_x = [&](int b, int h0, int w0, char *buf, int i0 = 0, int i1 = R6_XBUF / (R6_NT * 16)) {
+    // the tile's 18 x 18 x 64 input patch -> LDS: slot s = 10 * pixel + chunk, chunks 8 and 9 are padding (not written).
+    // A tile whose patch lies inside the picture (4 of 5 at 304 x 304) takes per-lane offsets computed once per launch:
+    // two VALU instructions per loader pass instead of twenty (this kernel issues 1.4 VALU cycles per MFMA cycle).
+    constexpr int NPASS = R6_XBUF / (R6_NT * 16);
+#if R6_FASTPATH
+    int rel[NPASS];                                // byte offset of this lane's slot from the patch's first pixel, -1 = none
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int s = tid + R6_NT * i;
+        const int pos = (s * 6554) >> 16, c = s - pos * 10;
+        const int pr = (pos * 3641) >> 16, pc = pos - pr * R6_P;
+        rel[i] = (pos < R6_NPOS && c < 8) ? (pr * p.W + pc) * p.x_ld * 2 + c * 16 : -1;
+    }
+#endif
+    auto issue_x = [&](int b, int h0, int w0, char *buf, int i0 = 0, int i1 = NPASS) {
+#if R6_FASTPATH
+        if (h0 >= 1 && w0 >= 1 && h0 + R6_T + 1 <= p.H && w0 + R6_T + 1 <= p.W) {      // (wave-uniform)
+            const char *base = p.x + (long)((b * p.H + h0 - 1) * p.W + w0 - 1) * p.x_ld * 2;
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+                if (rel[i] >= 0) glds16(base + rel[i], buf + i * (R6_NT * 16) + wave * 1024);
+            return;
+        }
+#endif
         int tidv = tid;
         asm volatile("" : "+v"(tidv));             // (per-tile arithmetic on purpose: see conv_resblock128.hip)
 #pragma unroll
@@ -132,6 +157,7 @@ void resblock64_kernel(const R6Args p) {
             if (!R6_SPREAD) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R6_XBUF);
         }
         // ---- phase 1: y = leaky(W1 x + b1) on the patch: row blocks wave, wave + 8, wave + 16 ----------------------------
+        const bool interior = h0 >= 1 && w0 >= 1 && h0 + R6_T + 1 <= p.H && w0 + R6_T + 1 <= p.W;
         int frv = frow;                            // (opaque per tile: keeps phase 1's per-lane addresses out of scratch)
         asm volatile("" : "+v"(frv));
 #pragma unroll
@@ -148,9 +174,12 @@ void resblock64_kernel(const R6Args p) {
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
                         a1[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[kb][ni], xf[kb], a1[ni], 0, 0, 0);
-                const int pr = (pos * 3641) >> 16, pc = pos - pr * R6_P;
-                const int h = h0 - 1 + pr, w = w0 - 1 + pc;
-                const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;    // outside: the 3x3's zero padding
+                bool in = true;                    // outside the picture: the 3x3's zero padding
+                if (!(R6_FASTPATH && interior)) {
+                    const int pr = (pos * 3641) >> 16, pc = pos - pr * R6_P;
+                    const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+                    in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     f32x4 v = a1[ni];
