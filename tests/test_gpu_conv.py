@@ -302,6 +302,37 @@ def test_conv3x3_c32_kernel_equals_the_implicit_gemm(H, W, res, leaky, pads):
             np.testing.assert_array_equal(gpu_util.run_conv(x, k, b, 1, "bf16", **kw), got)
 
 
+@pytest.mark.parametrize("B,H,W,leaky,pads", [(3, 304, 304, True, ((0, 0), (0, 0))), (4, 296, 280, True, ((64, 0), (128, 16))),
+                                               (3, 306, 304, False, ((0, 0), (0, 0)))])
+def test_conv3x3s2_c64_kernel_equals_the_implicit_gemm(B, H, W, leaky, pads):
+    """3x3 stride 2, 64 -> 128 on a large map (Darknet-53 layer 5) runs on conv3x3s2_c64_kernel (weights in registers,
+    9 x 33 input patch resident in LDS): y3_conv2d_fused picks it by shape.  Against the oracle, and bit for bit against
+    the implicit-GEMM tiles it replaces (same MFMA chain per output): output widths / heights that are not tile
+    multiples, channel slices of wider buffers, with and without leaky."""
+    from yolo_amd import _lib
+    C, O = 64, 128
+    rng = np.random.default_rng(H + W)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, W, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((3, 3, C, O)) * np.sqrt(2.0 / (9 * C))).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    want = _ref(x, k, b, 2, leaky)
+    kw = dict(leaky=leaky, in_pad=pads[0], out_pad=pads[1])
+    got = gpu_util.run_conv(x, k, b, 2, "bf16", **kw)
+    assert got.shape == want.shape == (B, H // 2, W // 2, O)
+    assert np.all(np.abs(got - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = _lib.Y3_BF16, B, H, W, C, 64
+    d.out_h, d.out_w, d.out_c, d.out_ld, d.res_ld, d.ksize, d.stride, d.k_pad, d.n_pad = H // 2, W // 2, O, 128, 128, 3, 2, 576, 128
+    name = ctypes.create_string_buffer(96)
+    _lib.check(lib.y3_conv_kernel_name(ctypes.byref(d), name, 96))
+    assert name.value.decode() == "conv3x3s2_c64_kernel"
+    with _lib.experimental() as exp:
+        for tile in (257, 128):
+            _lib.check(exp.y3_set_conv_tile(tile))
+            np.testing.assert_array_equal(gpu_util.run_conv(x, k, b, 2, "bf16", **kw), got)
+
+
 @pytest.mark.parametrize("case", ["ring_ups", "ring_1x1_res", "head_f32_256tile"])
 def test_conv_bench_scale_defaults(case):
     """Kernel choices that only engage at bench-scale pixel counts (M >= 65 536), against the oracle: the

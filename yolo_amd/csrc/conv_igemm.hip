@@ -1219,6 +1219,10 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
     if (!hd && splits <= 1 && g_conv_tile == 0 && g_conv_debug == 0 && (a.flags & CONV_REG_EPILOGUE) &&
         y3_conv_c32_ok(d, M * (long)d->out_ld * 2, (d->flags & Y3_CONV_RESIDUAL) ? M * (long)d->res_ld * 2 : 0L))
         return y3_conv_c32_launch(d, in, w, bias, residual, out, zeros, stream);
+    // 3x3 stride 2, 64 -> 128 on a large map (Darknet-53 layer 5): the same recipe (conv_s2c64.hip)
+    if (!hd && splits <= 1 && g_conv_tile == 0 && g_conv_debug == 0 && (a.flags & CONV_REG_EPILOGUE) &&
+        y3_conv_s2c64_ok(d, M * (long)d->out_ld * 2))
+        return y3_conv_s2c64_launch(d, in, w, bias, out, zeros, stream);
     if (hd) {                                      // fused head decode: only the two tiles that carry it
         Y3_REQUIRE(bf16 && !(a.flags & CONV_REG_EPILOGUE) && d->n_pad == 256, Y3_E_INVALID, "conv_head_decode: not a bf16 -> fp32 head launch");
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream, hd);
@@ -1456,6 +1460,10 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     if (d->dtype == Y3_BF16 && g_conv_tile == 0 && g_conv_debug == 0 && d->out_ld > 0 &&
         y3_conv_c32_ok(d, M * (long)d->out_ld * 2, (d->flags & Y3_CONV_RESIDUAL) ? M * (long)d->res_ld * 2 : 0L)) {
         snprintf(buf, (size_t)len, "conv3x3_c32_kernel");
+        return Y3_OK;
+    }
+    if (d->dtype == Y3_BF16 && g_conv_tile == 0 && g_conv_debug == 0 && d->out_ld > 0 && y3_conv_s2c64_ok(d, M * (long)d->out_ld * 2)) {
+        snprintf(buf, (size_t)len, "conv3x3s2_c64_kernel");
         return Y3_OK;
     }
     const int v = conv_variant(d, M);
