@@ -30,6 +30,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define R1_ABLATE 0         // timing experiments (tools/ab_build.sh builds only, garbage results): 1 no phase 1, 2 no phase 2,
 #endif                      // 4 no next-patch loads, 8 no stores
 
+#ifndef R1_SPREAD
+#define R1_SPREAD 1                                // loader passes among phase 2's first taps (0: all at the top of the tile)
+#endif
+#ifndef R1_FASTPATH
+#define R1_FASTPATH 0                              // interior tiles: loader offsets from registers (conv_resblock64.hip) -- here the
+                                                   // seven registers do not fit beside 144 of weights: 21 spilled, off
+#endif
 #ifndef R1_PHASE1_PIPE
 #define R1_PHASE1_PIPE 1
 #endif
@@ -106,13 +113,33 @@ void resblock128_kernel(const R1Args p) {
         w0 = (ti - ty * p.tiles_x) * R1_TW;
     };
     // the tile's 10 x 18 x 128 input patch -> LDS: slot s = 18 * pixel + chunk, chunks 16 and 17 are padding (not written)
-    auto issue_x = [&](int b, int h0, int w0, char *buf) {
+    constexpr int NPASS = R1_XBUF / (R1_NT * 16);
+#if R1_FASTPATH
+    int rel[NPASS];                                // interior tiles: byte offset of this lane's slot from the patch's first pixel, -1 = none
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int s = tid + R1_NT * i;
+        const int pos = (s * 3641) >> 16, c = s - pos * 18;
+        const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;
+        rel[i] = (pos < R1_NPOS && c < 16) ? (pr * p.W + pc) * p.x_ld * 2 + c * 16 : -1;
+    }
+#endif
+    auto issue_x = [&](int b, int h0, int w0, char *buf, int i0 = 0, int i1 = NPASS) {
+#if R1_FASTPATH
+        if (h0 >= 1 && w0 >= 1 && h0 + R1_TH + 1 <= p.H && w0 + R1_TW + 1 <= p.W) {    // (wave-uniform)
+            const char *base = p.x + (long)((b * p.H + h0 - 1) * p.W + w0 - 1) * p.x_ld * 2;
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+                if (rel[i] >= 0) glds16(base + rel[i], buf + i * (R1_NT * 16) + wave * 1024);
+            return;
+        }
+#endif
         // (the slot -> pixel arithmetic is recomputed per tile on purpose: hoisted out of the tile loop its 7 x 4 values
         // push the kernel past 256 registers and hipcc reloads them from scratch behind vmcnt(0) waits)
         int tidv = tid;
         asm volatile("" : "+v"(tidv));
 #pragma unroll
-        for (int i = 0; i < R1_XBUF / (R1_NT * 16); ++i) {
+        for (int i = i0; i < i1; ++i) {
             const int s = tidv + R1_NT * i;
             const int pos = (s * 3641) >> 16, c = s - pos * 18;                   // s / 18, exact below 4096
             const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;             // pos / 18
@@ -144,9 +171,10 @@ void resblock128_kernel(const R1Args p) {
         const char *xb = smem + cur * R1_XBUF;
         const int next = tile + (int)gridDim.x;
         int nb = 0, nh0 = 0, nw0 = 0;
-        if (next < p.total_tiles) {                // the next tile's patch travels under this tile's MFMAs
+        const bool more = next < p.total_tiles && !(R1_ABLATE & 4);
+        if (more) {                                // the next tile's patch travels under this tile's MFMAs
             tile_coords(next, nb, nh0, nw0);
-            if (!(R1_ABLATE & 4)) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R1_XBUF);
+            if (!R1_SPREAD) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R1_XBUF);
         }
         // ---- phase 1: y = leaky(W1 x + b1) on the patch -----------------------------------------------------------
         int frv = frow;                            // (opaque per tile: keeps phase 1's per-lane addresses out of scratch,
@@ -269,6 +297,12 @@ void resblock128_kernel(const R1Args p) {
                     for (int ni = 0; ni < 2; ++ni)
                         acc[ni][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[t][kb][ni], yf[kb][r], acc[ni][r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            // (R1_SPREAD) one loader pass after each of the first taps: an LDS-DMA instruction holds its wave for 60-180
+            // cycles, which the SIMD's other wave fills with MFMAs here and cannot at the top of the tile
+            if (R1_SPREAD && t < NPASS) {
+                if (more) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R1_XBUF, t, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- epilogue: leaky, pairing, + x (the patch's centre, from LDS) in fp32, one bf16 rounding, 16-byte stores ----
         const int w = w0 + frow;
