@@ -195,14 +195,14 @@ void resblock128_kernel(const R1Args p) {
 #pragma unroll
             for (int j = 0; j < ((R1_ABLATE & 1) ? 0 : 3); ++j) {
                 const int pos = ((wave + 8 * j) >> 1) * 16 + frv;
-#if R1_PHASE1_PIPE > 1
+#if R1_PHASE1_PIPE == 2
                 bf16x8 xn[4];
                 if (j < 2) {
                     const int posn = ((wave + 8 * (j + 1)) >> 1) * 16 + frv;
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) xn[kb] = *(const bf16x8 *)(xb + posn * R1_XP + (kb * 4 + fq) * 16);
                 }
-#else
+#elif R1_PHASE1_PIPE == 1
                 if (j > 0) {
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + pos * R1_XP + (kb * 4 + fq) * 16);
@@ -215,6 +215,14 @@ void resblock128_kernel(const R1Args p) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) a1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][kb], xf[kb], a1[q], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#if R1_PHASE1_PIPE == 3
+                if (j < 2) {                       // the next row block's fragments travel under this one's leaky / pack / store
+                    const int posn = ((wave + 8 * (j + 1)) >> 1) * 16 + frv;
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + posn * R1_XP + (kb * 4 + fq) * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
                 const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;
                 const int h = h0 - 1 + pr, w = w0 - 1 + pc;
                 const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;    // outside: the 3x3's zero padding
@@ -226,7 +234,7 @@ void resblock128_kernel(const R1Args p) {
                     const unsigned o0 = in ? pack_bf16x2(v[0], v[1]) : 0u, o1 = in ? pack_bf16x2(v[2], v[3]) : 0u;
                     if (pos < R1_NPOS) lds_store8_unordered(ybuf + pos * R1_YP + ((nip * 2 + q) * 16 + fq * 4) * 2, o0, o1);
                 }
-#if R1_PHASE1_PIPE > 1
+#if R1_PHASE1_PIPE == 2
                 if (j < 2) {
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) xf[kb] = xn[kb];

@@ -261,6 +261,7 @@ long y3_resblock64_tiles(int batch, int h, int w) {
 int y3_resblock64_launch(const y3_resblock_desc *d, const void *x, const void *w1, const float *b1, const void *w2,
                          const float *b2, void *out, const void *zeros, hipStream_t stream) {
     const long pixels = (long)d->batch * d->h * d->w;
+    Y3_REQUIRE((long)R6_P * d->w * d->x_ld * 2 < 0x7fffffffL, Y3_E_INVALID, "resblock64: rows of %d x %d elements are too long", d->w, d->x_ld);
     R6Args a;
     a.x = (const char *)x; a.w1 = (const char *)w1; a.w2 = (const char *)w2; a.zeros = (const char *)zeros;
     a.b1 = b1; a.b2 = b2; a.out = (char *)out;

@@ -197,7 +197,8 @@ bool y3_conv_s2c64_ok(const y3_conv_desc *d, long out_bytes) {
     if (d->k_pad != S2_KPAD || d->n_pad != 128) return false;
     if (d->flags & (Y3_CONV_UPS2X | Y3_CONV_OUT_F32 | Y3_CONV_IN_F32 | Y3_CONV_POOL2 | Y3_CONV_RESIDUAL)) return false;
     if (d->in_h != 2 * d->out_h || d->in_w != 2 * d->out_w) return false;         // (even input: out = in / 2, pad top/left)
-    if (out_bytes >= 0xffff0000L || (long)d->batch * d->in_h * d->in_w * d->in_ld * 2 >= 0x7fffffffL) return false;
+    if (out_bytes >= 0xffff0000L || (long)d->batch * d->in_h * d->in_w >= 0x7fffffffL) return false;   // (pixel indices are ints;
+    if ((long)S2_PH * d->in_w * d->in_ld * 2 >= 0x7fffffffL) return false;                                  //  so are offsets in a patch)
     // worth it only when the launch fills the chip several times over (persistent workgroups, weights loaded once each)
     const long tiles = s2_tiles(d);
     return tiles >= 4L * y3_device_cus() && tiles < 0x7fffffffL;
