@@ -30,6 +30,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define R1_ABLATE 0         // timing experiments (tools/ab_build.sh builds only, garbage results): 1 no phase 1, 2 no phase 2,
 #endif                      // 4 no next-patch loads, 8 no stores
 
+#ifndef R1_P2_PIPE
+#define R1_P2_PIPE 1                               // phase 2: fragment reads of the next tap under this tap's MFMAs
+#endif
 #ifndef R1_SPREAD
 #define R1_SPREAD 1                                // loader passes among phase 2's first taps (0: all at the top of the tile)
 #endif
@@ -55,7 +58,8 @@ constexpr int R1_YROWS = (R1_NPOS + 15) / 16 * 16; // 192: phase 1 runs on 12 ro
 constexpr int R1_YBUF = R1_NPOS * R1_YP;           // (row blocks past the patch are computed but not stored)
 constexpr int R1_W1P = 288;                        // bytes between rows of W1 in LDS (256 + 32: conflict-free fragment reads)
 constexpr int R1_W1BUF = 64 * R1_W1P;
-constexpr int R1_LDS = 2 * R1_XBUF + R1_YBUF + R1_W1BUF;      // 161 920 of 163 840 bytes
+constexpr int R1_BIASBUF = (64 + 128) * 4;         // b1 | b2 as fp32 (16 registers that phase 2's pipelined fragment reads need)
+constexpr int R1_LDS = 2 * R1_XBUF + R1_YBUF + R1_W1BUF + R1_BIASBUF;     // 162 688 of 163 840 bytes
 static_assert(R1_LDS <= 160 * 1024, "LDS budget");
 static_assert(R1_YROWS * R1_XP <= R1_XBUF, "phase 1 reads whole row blocks of the x patch buffer");
 
@@ -74,6 +78,7 @@ void resblock128_kernel(const R1Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const ybuf = smem + 2 * R1_XBUF;
     char *const w1buf = ybuf + R1_YBUF;
+    const char *const biasbuf = w1buf + R1_W1BUF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
@@ -90,13 +95,12 @@ void resblock128_kernel(const R1Args p) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
                 wf2[t][kb][ni] = *(const bf16x8 *)(p.w2 + ((32 * wn + 16 * ni + frow) * 576 + t * 64 + kb * 32 + fq * 8) * 2);
-    f32x4 bias2[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) bias2[ni] = *(const f32x4 *)(p.b2 + 32 * wn + 16 * ni + fq * 4);
     const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;      // after the swap pairing: this lane's first channel of the 32
-    f32x4 bias1[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bias1[j] = *(const f32x4 *)(p.b1 + (nip * 2 + j) * 16 + fq * 4);
+    // biases -> LDS (read back per tile as the accumulators' initial values)
+    if (tid < 64) ((float *)biasbuf)[tid] = p.b1[tid];
+    else if (tid < 192) ((float *)biasbuf)[tid] = p.b2[tid - 64];
+    auto bias1 = [&](int j) { return *(const f32x4 *)(biasbuf + ((nip * 2 + j) * 16 + fq * 4) * 4); };
+    auto bias2 = [&](int ni) { return *(const f32x4 *)(biasbuf + 256 + (32 * wn + 16 * ni + fq * 4) * 4); };
     // W1 [64][128] bf16 -> LDS, rows 288 bytes apart (the first barrier of the tile loop publishes it)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -209,7 +213,7 @@ void resblock128_kernel(const R1Args p) {
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 a1[2] = {bias1[0], bias1[1]};
+                f32x4 a1[2] = {bias1(0), bias1(1)};
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -247,7 +251,7 @@ void resblock128_kernel(const R1Args p) {
         for (int j = 0; j < ((R1_ABLATE & 1) ? 0 : 3); ++j) {
             const int blk = (wave + 8 * j) >> 1;   // row block 0..11 of this (row block, block pair) unit
             const int pos = blk * 16 + frv;
-            f32x4 a1[2] = {bias1[0], bias1[1]};
+            f32x4 a1[2] = {bias1(0), bias1(1)};
             bf16x8 xf[4];                          // fragment reads in two batches of eight and four, each ahead of its MFMAs
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + pos * R1_XP + (kb * 4 + fq) * 16);
@@ -283,7 +287,47 @@ void resblock128_kernel(const R1Args p) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ni][r] = bias2[ni];
+            for (int r = 0; r < 4; ++r) acc[ni][r] = bias2(ni);
+#if R1_P2_PIPE
+        // Software pipeline at half-tap granularity, register-neutral: the four fragments of k-block kb are re-read for the
+        // NEXT tap right after this tap's eight MFMAs of that k-block have been issued, so the LDS round trip runs under
+        // the other k-block's MFMAs.  (All eight waves leave the barrier together: un-pipelined they all read, then all
+        // multiply, and the LDS array and the MFMA pipes take turns idling.)
+        {
+            bf16x8 yf[2][4];
+            int yoff = frow * R1_YP + fq * 16;     // (opaque per tile: one address register and immediate offsets, not 72 hoisted addresses)
+            asm volatile("" : "+v"(yoff));
+            const char *ylane = ybuf + yoff;
+            auto rd = [&](int t, int kb) {
+                const int dh = t / 3, dw = t - 3 * dh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    yf[kb][r] = *(const bf16x8 *)(ylane + ((4 * wm + r + dh) * R1_PW + dw) * R1_YP + kb * 64);
+            };
+            rd(0, 0);
+            rd(0, 1);
+            constexpr int NT9 = (R1_ABLATE & 2) ? 1 : 9;
+#pragma unroll
+            for (int t = 0; t < NT9; ++t) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[ni][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[t][kb][ni], yf[kb][r], acc[ni][r], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < NT9) rd(t + 1, kb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (R1_SPREAD && t < NPASS) {
+                    if (more) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R1_XBUF, t, t + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int t = 0; t < ((R1_ABLATE & 2) ? 1 : 9); ++t) {
             const int dh = t / 3, dw = t - 3 * dh;
@@ -312,6 +356,7 @@ void resblock128_kernel(const R1Args p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
         // ---- epilogue: leaky, pairing, + x (the patch's centre, from LDS) in fp32, one bf16 rounding, 16-byte stores ----
         const int w = w0 + frow;
 #pragma unroll
