@@ -30,6 +30,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define R1_ABLATE 0         // timing experiments (tools/ab_build.sh builds only, garbage results): 1 no phase 1, 2 no phase 2,
 #endif                      // 4 no next-patch loads, 8 no stores
 
+#ifndef R1_P1_INTERIOR
+#define R1_P1_INTERIOR 0                           // phase 1 skips the in-picture test on tiles whose patch lies inside the picture
+#endif
 #ifndef R1_P2_PIPE
 #define R1_P2_PIPE 1                               // phase 2: fragment reads of the next tap under this tap's MFMAs
 #endif
@@ -181,6 +184,7 @@ void resblock128_kernel(const R1Args p) {
             if (!R1_SPREAD) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R1_XBUF);
         }
         // ---- phase 1: y = leaky(W1 x + b1) on the patch -----------------------------------------------------------
+        const bool interior = h0 >= 1 && w0 >= 1 && h0 + R1_TH + 1 <= p.H && w0 + R1_TW + 1 <= p.W;   // (wave-uniform)
         int frv = frow;                            // (opaque per tile: keeps phase 1's per-lane addresses out of scratch,
         asm volatile("" : "+v"(frv));              // where hipcc parks them as loop invariants and reloads behind vmcnt(0))
 #if R1_PHASE1_PIPE
@@ -227,9 +231,12 @@ void resblock128_kernel(const R1Args p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
-                const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;
-                const int h = h0 - 1 + pr, w = w0 - 1 + pc;
-                const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;    // outside: the 3x3's zero padding
+                bool in = true;                    // outside the picture: the 3x3's zero padding
+                if (!(R1_P1_INTERIOR && interior)) {
+                    const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;
+                    const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+                    in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     f32x4 v = a1[q];
