@@ -333,6 +333,36 @@ def test_conv3x3s2_c64_kernel_equals_the_implicit_gemm(B, H, W, leaky, pads):
             np.testing.assert_array_equal(gpu_util.run_conv(x, k, b, 2, "bf16", **kw), got)
 
 
+@pytest.mark.parametrize("B,H,W,C,O,leaky,pads", [(48, 38, 38, 512, 256, True, ((0, 0), (0, 0))), (12, 76, 76, 256, 128, True, ((0, 0), (0, 0))),
+                                                   (3, 150, 153, 256, 128, False, ((128, 0), (64, 192))),
+                                                   (5, 117, 119, 512, 256, True, ((0, 256), (256, 0))), (12, 76, 76, 384, 128, True, ((0, 0), (0, 0)))])
+def test_conv1x1_regw_kernel_equals_the_implicit_gemm(B, H, W, C, O, leaky, pads):
+    """The residual stages' 1x1 bottlenecks (512 -> 256, 256 -> 128) on large launches run on conv1x1_regw_kernel (the
+    whole weight matrix in registers, 64-pixel tiles of activations through LDS): y3_conv2d_fused picks it by shape.
+    Against the oracle, and bit for bit against the implicit-GEMM tiles it replaces (same MFMA chain per output): pixel
+    counts that are not tile multiples, channel slices of wider buffers (route inputs / concat outputs)."""
+    from yolo_amd import _lib
+    rng = np.random.default_rng(H + W + C)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, W, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((1, 1, C, O)) * np.sqrt(2.0 / C)).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    want = _ref(x, k, b, 1, leaky)
+    kw = dict(leaky=leaky, in_pad=pads[0], out_pad=pads[1])
+    got = gpu_util.run_conv(x, k, b, 1, "bf16", **kw)
+    assert np.all(np.abs(got - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = _lib.Y3_BF16, B, H, W, C, C
+    d.out_h, d.out_w, d.out_c, d.out_ld, d.res_ld, d.ksize, d.stride, d.k_pad, d.n_pad = H, W, O, O, O, 1, 1, C, O
+    name = ctypes.create_string_buffer(96)
+    _lib.check(lib.y3_conv_kernel_name(ctypes.byref(d), name, 96))
+    assert name.value.decode() == "conv1x1_regw_kernel<%d, %d>" % (C, O)
+    with _lib.experimental() as exp:
+        for tile in ((256, 192, 128) if O == 256 else (257, 128)):
+            _lib.check(exp.y3_set_conv_tile(tile))
+            np.testing.assert_array_equal(gpu_util.run_conv(x, k, b, 1, "bf16", **kw), got)
+
+
 @pytest.mark.parametrize("case", ["ring_ups", "ring_1x1_res", "head_f32_256tile"])
 def test_conv_bench_scale_defaults(case):
     """Kernel choices that only engage at bench-scale pixel counts (M >= 65 536), against the oracle: the

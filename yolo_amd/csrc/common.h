@@ -85,6 +85,9 @@ int y3_conv_c32_launch(const y3_conv_desc *d, const void *in, const void *w, con
 bool y3_conv_s2c64_ok(const y3_conv_desc *d, long out_bytes);
 int y3_conv_s2c64_launch(const y3_conv_desc *d, const void *in, const void *w, const float *bias, void *out,
                          const void *zeros, hipStream_t stream);
+bool y3_conv_1x1w_ok(const y3_conv_desc *d, long out_bytes);
+int y3_conv_1x1w_launch(const y3_conv_desc *d, const void *in, const void *w, const float *bias, void *out,
+                        const void *zeros, hipStream_t stream);
 
 // conv_resblock128.hip: the 128-channel residual block (y3_resblock_fused dispatches to it)
 long y3_resblock128_tiles(int batch, int h, int w);

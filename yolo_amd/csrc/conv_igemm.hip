@@ -1223,6 +1223,10 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
     if (!hd && splits <= 1 && g_conv_tile == 0 && g_conv_debug == 0 && (a.flags & CONV_REG_EPILOGUE) &&
         y3_conv_s2c64_ok(d, M * (long)d->out_ld * 2))
         return y3_conv_s2c64_launch(d, in, w, bias, out, zeros, stream);
+    // 1x1 512 -> 256 / 256 -> 128 on large launches: the whole weight matrix in registers (conv_1x1w.hip)
+    if (!hd && splits <= 1 && g_conv_tile == 0 && g_conv_debug == 0 && (a.flags & CONV_REG_EPILOGUE) &&
+        y3_conv_1x1w_ok(d, M * (long)d->out_ld * 2))
+        return y3_conv_1x1w_launch(d, in, w, bias, out, zeros, stream);
     if (hd) {                                      // fused head decode: only the two tiles that carry it
         Y3_REQUIRE(bf16 && !(a.flags & CONV_REG_EPILOGUE) && d->n_pad == 256, Y3_E_INVALID, "conv_head_decode: not a bf16 -> fp32 head launch");
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream, hd);
@@ -1464,6 +1468,10 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     }
     if (d->dtype == Y3_BF16 && g_conv_tile == 0 && g_conv_debug == 0 && d->out_ld > 0 && y3_conv_s2c64_ok(d, M * (long)d->out_ld * 2)) {
         snprintf(buf, (size_t)len, "conv3x3s2_c64_kernel");
+        return Y3_OK;
+    }
+    if (d->dtype == Y3_BF16 && g_conv_tile == 0 && g_conv_debug == 0 && d->out_ld > 0 && y3_conv_1x1w_ok(d, M * (long)d->out_ld * 2)) {
+        snprintf(buf, (size_t)len, "conv1x1_regw_kernel<%d, %d>", d->in_c, d->out_c);
         return Y3_OK;
     }
     const int v = conv_variant(d, M);
