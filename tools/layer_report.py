@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--no-stem", action="store_true")
     ap.add_argument("--splitk", action="store_true")
     ap.add_argument("--no-resblock", action="store_true", help="residual blocks as two launches (1x1, 3x3 + shortcut)")
+    ap.add_argument("--decode", action="store_true", help="time the step's launches with the decode fused into the head convolutions")
     ap.add_argument("--phase", type=int, default=-1, help="de-phasing offset in percent of a tile period (0 = off)")
     a = ap.parse_args()
     cfg = config.yolov3_tiny_cfg_path if a.model == "yolov3-tiny" else config.yolov3_cfg_path
@@ -38,13 +39,24 @@ def main():
                               resblock=False if a.no_resblock else None)
     net.set_params(dw.random_params(net.layers, seed=0))
     x = torch.rand((a.batch, a.size, a.size, 3), device="cuda")
+    pp = None
+    if a.decode:
+        from yolo_amd import inference
+        anchors = inference.read_anchors(config.tiny_anchors_path if a.model == "yolov3-tiny" else config.anchors_path)
+        pp = inference._postprocessor(anchors, config.num_classes, (a.size, a.size))
+
+    def run(trace=None):
+        if pp is not None:
+            pp.detect(net, x, (a.size, a.size), chunk=a.chunk or None, trace=trace)
+        else:
+            net.forward(x, chunk=a.chunk or None, trace=trace)
     for _ in range(2):
-        net.forward(x, chunk=a.chunk or None)
+        run()
     torch.cuda.synchronize()
     acc = {}
     for _ in range(a.reps):
         tr = []
-        net.forward(x, chunk=a.chunk or None, trace=tr)
+        run(tr)
         torch.cuda.synchronize()
         for i, (op, e0, e1) in enumerate(tr):
             acc.setdefault(i, [op, []])[1].append(e0.elapsed_time(e1))

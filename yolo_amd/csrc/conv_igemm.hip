@@ -39,6 +39,10 @@
 #include "decode_box.h"
 #include <type_traits>
 
+#ifndef Y3_DEC_ABLATE
+#define Y3_DEC_ABLATE 0
+#endif
+
 namespace {
 
 #ifdef Y3_EXPERIMENTS
@@ -241,14 +245,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
                 const int gy = fast_div(cell, p.fd_wo), gx = cell - gy * p.Wo;
                 const float scale = hd->letterbox[b * 4 + 0], off_h = hd->letterbox[b * 4 + 1], off_w = hd->letterbox[b * 4 + 2];
                 float *tl = Cs + (live ? row : 0) * CS_LD + an * E;
+#if Y3_DEC_ABLATE & 1                              // (timing experiments, A/B builds only: results are garbage)
+                DecodedBox o;
+                o.ymin = o.xmin = o.ymax = o.xmax = tl[0]; o.score = tl[4]; o.m0 = o.m1 = o.m2 = 0u;
+#else
                 const DecodedBox o = y3_decode_box(tl, live, C, gx, gy, hd->stride_x, hd->stride_y, hd->anchor[an][0],
                                                    hd->anchor[an][1], scale, off_h, off_w);
+#endif
                 const int pbox = hd->scale_base + cell * 3 + an;
                 if (live) {
                     float *r = hd->records + ((long)b * hd->N + pbox) * 8;
                     *(f32x4 *)r = f32x4{o.ymin, o.xmin, o.ymax, o.xmax};
                     *(f32x4 *)(r + 4) = f32x4{o.score, __uint_as_float(o.m0), __uint_as_float(o.m1), __uint_as_float(o.m2)};
-                    if (o.score >= hd->thr) {                                          // inference.py:127
+                    if (!(Y3_DEC_ABLATE & 2) && o.score >= hd->thr) {                  // inference.py:127
                         const int slot = b - b_lo;
                         s_list[slot][atomicAdd(&s_cnt[slot], 1)] = pbox;
                         unsigned mm[3] = {o.m0, o.m1, o.m2};
