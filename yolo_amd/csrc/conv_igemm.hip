@@ -100,6 +100,15 @@ __device__ __forceinline__ void row_setup(const ConvArgs &p, int gm, int es, lon
 
 constexpr int CONV_NO_BIAS = 1 << 24;    // internal flag: split-K partial sums carry no bias
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global access
+// (s_waitcnt vmcnt(0)): in the decode epilogue that would put the record stores, the candidate stores and a global
+// atomic's round trip on the critical path of every pass.
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Head decode fused into a head convolution's epilogue (y3_conv2d_head_decode): what y3_decode needs for ONE scale.
 struct HeadDecode {
     const float *letterbox;              // [B][4]: scale, off_h, off_w (utils/utils.py:100-116)
@@ -109,6 +118,9 @@ struct HeadDecode {
     float stride_x, stride_y, thr;
     float anchor[3][2];
 };
+
+// LDS of the decode epilogue behind the staged tile: s_cnt[2] | s_hist[2][96] | s_base[2] | s_list[2][EP_ROWS * 3] (ints)
+constexpr int dec_cnt_bytes(int ep_rows) { return (2 + 2 * 96 + 2 + 2 * ep_rows * 3) * 4; }
 
 // Epilogue shared by the convolution kernels: accumulators -> LDS (fp32) -> bias, leaky, residual ->
 // NHWC rows with 16-byte stores, EP_ROWS tile rows per pass.
@@ -145,7 +157,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
                 if constexpr (!BF16) rv[i][1] = *(const u32x4 *)(rp + 16);
             }
         }
-        __syncthreads();                       // LDS tiles / previous pass fully consumed
+        // (decode epilogue: per-box constants requested here, ahead of the LDS round trip, not after its barrier)
+        [[maybe_unused]] int d_b = 0, d_cell = 0;
+        [[maybe_unused]] float d_scale = 1.0f, d_offh = 0.0f, d_offw = 0.0f;
+        [[maybe_unused]] bool d_live = false;
+        if constexpr (DECODE) {
+            const int row = tid / 3, gm = m0 + pass * EP_ROWS + row;
+            d_live = tid < EP_ROWS * 3 && gm < p.M;
+            const int gmc = d_live ? gm : min(m0 + pass * EP_ROWS, p.M - 1);
+            d_b = fast_div(gmc, p.fd_howo);
+            d_cell = gmc - d_b * p.HoWo;
+            d_scale = hd->letterbox[d_b * 4 + 0]; d_offh = hd->letterbox[d_b * 4 + 1]; d_offw = hd->letterbox[d_b * 4 + 2];
+        }
+        if (DECODE && pass > 0) lds_only_barrier();    // (the previous pass's global stores and atomics stay in flight)
+        else __syncthreads();                  // LDS tiles / previous pass fully consumed
+        if constexpr (DECODE) {                // candidate counters of this pass (read last before the barrier above)
+            int *cz = (int *)(smem + EP_ROWS * CS_LD * 4);
+            if (tid < 2 + 2 * 96) cz[tid] = 0;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int rb = wm * TM + mi * 16 - pass * EP_ROWS;       // wave-uniform
@@ -158,7 +187,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
                 *(f32x4 *)(Cs + (rb + frow) * CS_LD + n) = v;
             }
         }
-        __syncthreads();
+        if constexpr (DECODE) lds_only_barrier();
+        else __syncthreads();
 #pragma unroll
         for (int i = 0; i < O_IT; ++i) {
             if constexpr (DECODE) {
@@ -225,32 +255,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
         if constexpr (DECODE) {
             // ---- head decode of this pass's EP_ROWS grid cells x 3 anchors, straight from the staged fp32 values --------
             // (what decode_lane_kernel does after copying the head back from HBM: same per-box code, decode_box.h)
-            __shared__ int s_cnt[2], s_base[2];
-            __shared__ int s_hist[2][96];
-            __shared__ int s_list[2][EP_ROWS * 3];
+            int *const s_cnt = (int *)(smem + EP_ROWS * CS_LD * 4);             // [2]         (zeroed at the top of the pass)
+            int *const s_hist = s_cnt + 2;                                      // [2][96]
+            int *const s_base = s_hist + 2 * 96;                                // [2]
+            int *const s_list = s_base + 2;                                     // [2][EP_ROWS * 3]
             const int C = hd->C, E = 5 + C;
             const int row0 = m0 + pass * EP_ROWS;
             if (row0 >= p.M) break;                                  // block-uniform
             const int b_lo = fast_div(row0, p.fd_howo);              // a pass spans at most two images (HoWo >= EP_ROWS)
-            if (tid < 2) s_cnt[tid] = 0;
-            if (tid < 2 * 96) (&s_hist[0][0])[tid] = 0;
-            __syncthreads();                                         // the head stores above have read Cs; counters are clear
+            if (hd->store_heads) lds_only_barrier();                 // the head stores above have read Cs (decode writes into it)
             if ((tid & ~63) < EP_ROWS * 3) {                         // wave-uniform
                 const int row = tid / 3, an = tid - row * 3;
-                const int gm = row0 + row;
-                const bool live = tid < EP_ROWS * 3 && gm < p.M;
-                const int gmc = live ? gm : row0;
-                const int b = fast_div(gmc, p.fd_howo);
-                const int cell = gmc - b * p.HoWo;
+                const bool live = d_live;
+                const int b = d_b, cell = d_cell;
                 const int gy = fast_div(cell, p.fd_wo), gx = cell - gy * p.Wo;
-                const float scale = hd->letterbox[b * 4 + 0], off_h = hd->letterbox[b * 4 + 1], off_w = hd->letterbox[b * 4 + 2];
                 float *tl = Cs + (live ? row : 0) * CS_LD + an * E;
 #if Y3_DEC_ABLATE & 1                              // (timing experiments, A/B builds only: results are garbage)
                 DecodedBox o;
                 o.ymin = o.xmin = o.ymax = o.xmax = tl[0]; o.score = tl[4]; o.m0 = o.m1 = o.m2 = 0u;
 #else
                 const DecodedBox o = y3_decode_box(tl, live, C, gx, gy, hd->stride_x, hd->stride_y, hd->anchor[an][0],
-                                                   hd->anchor[an][1], scale, off_h, off_w);
+                                                   hd->anchor[an][1], d_scale, d_offh, d_offw);
 #endif
                 const int pbox = hd->scale_base + cell * 3 + an;
                 if (live) {
@@ -259,25 +284,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
                     *(f32x4 *)(r + 4) = f32x4{o.score, __uint_as_float(o.m0), __uint_as_float(o.m1), __uint_as_float(o.m2)};
                     if (!(Y3_DEC_ABLATE & 2) && o.score >= hd->thr) {                  // inference.py:127
                         const int slot = b - b_lo;
-                        s_list[slot][atomicAdd(&s_cnt[slot], 1)] = pbox;
+                        s_list[slot * (EP_ROWS * 3) + atomicAdd(&s_cnt[slot], 1)] = pbox;
                         unsigned mm[3] = {o.m0, o.m1, o.m2};
                         for (int w = 0; w < 3; ++w)
-                            while (mm[w]) { const int bit = __ffs(mm[w]) - 1; mm[w] &= mm[w] - 1; atomicAdd(&s_hist[slot][w * 32 + bit], 1); }
+                            while (mm[w]) { const int bit = __ffs(mm[w]) - 1; mm[w] &= mm[w] - 1; atomicAdd(&s_hist[slot * 96 + w * 32 + bit], 1); }
                     }
                 }
             }
-            __syncthreads();
+            lds_only_barrier();                                      // lists and counts complete (the record stores stay in flight)
             if (tid < 2 && s_cnt[tid]) s_base[tid] = atomicAdd(&hd->cand_count[b_lo + tid], s_cnt[tid]);
             if (tid < 2 * 96) {
                 const int slot = tid / 96, c = tid - slot * 96;
-                const int h = s_hist[slot][c];
+                const int h = s_hist[slot * 96 + c];
                 if (c < C && h) atomicAdd(&hd->class_count[(b_lo + slot) * C + c], h);
             }
-            __syncthreads();
+            lds_only_barrier();                                      // (the two lanes that own s_base waited for their atomics' results)
 #pragma unroll
             for (int slot = 0; slot < 2; ++slot) {
                 const int n = s_cnt[slot];
-                for (int i = tid; i < n; i += NT) hd->cand_idx[(long)(b_lo + slot) * hd->N + s_base[slot] + i] = s_list[slot][i];
+                for (int i = tid; i < n; i += NT)
+                    hd->cand_idx[(long)(b_lo + slot) * hd->N + s_base[slot] + i] = s_list[slot * (EP_ROWS * 3) + i];
             }
         }
     }
@@ -966,7 +992,7 @@ void conv_direct_pool_kernel(const DirectArgs p) {
 template <bool BF16, int BM, int BN, int WM, int WN, int EP_ROWS, bool IL, bool DEC = false>
 int launch_igemm_(ConvArgs a, int n_pad, hipStream_t stream, const HeadDecode *hd = nullptr) {
     constexpr int stage_bytes = 2 * (BM + BN) * 128;
-    constexpr int cs_bytes = EP_ROWS * (BN + 4) * 4;
+    constexpr int cs_bytes = EP_ROWS * (BN + 4) * 4 + (DEC ? dec_cnt_bytes(EP_ROWS) : 0);     // (+ the decode epilogue's candidate lists)
     constexpr int lds = stage_bytes > cs_bytes ? stage_bytes : cs_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv_igemm_kernel<BF16, BM, BN, WM, WN, EP_ROWS, IL, DEC>;
