@@ -18,8 +18,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWsHeader = 128;      // ints before a bucketed image's candidate list: start[0..C]
-constexpr int kSlots = 2;          // candidates per lane in nms_wave_kernel: up to 128 per (image, class) pair
-constexpr int kBSlots = 4;         // candidates per lane in nms_block_kernel (256 threads): up to 1024 per pair
+constexpr int kSlots = 2;          // candidates per lane in nms_wave_tier: up to 128 per (image, class) pair
+constexpr int kBSlots = 4;         // candidates per lane in nms_block_tier (256 threads): up to 1024 per pair
 constexpr int kBlockMax = kThreads * kBSlots;
 
 __device__ __forceinline__ bool iou_gt(const f32x4 bi, const f32x4 bj, float thr) {
@@ -88,7 +88,7 @@ __device__ __forceinline__ unsigned long long make_key(float score, int idx) {
 }
 
 // ws (nullable): per image, class-bucketed candidate lists from nms_bucket_kernel.  With it, pairs of at most
-// small_limit candidates belong to nms_wave_kernel / nms_block_kernel and are skipped here, and the others copy their
+// small_limit candidates belong to nms_tiers_kernel (nms_wave_tier / nms_block_tier) and are skipped here, and the others copy their
 // bucket instead of scanning the image's whole candidate list.
 __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, const int *cand_idx, const int *cand_count,
                                                        const int *class_count, int B, int N, int C, int max_boxes,
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
         }
         const int *wsb = ws ? ws + (long)b * ws_stride : nullptr;
         const bool bucketed = wsb && wsb[0] >= 0;                // block-uniform
-        if (bucketed && ncls <= small_limit) continue;           // nms_wave_kernel's or nms_block_kernel's
+        if (bucketed && ncls <= small_limit) continue;           // nms_tiers_kernel's
         __syncthreads();                                         // previous pair's LDS use is over
         if (tid == 0) s_n = 0;
         __syncthreads();
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(const float *records, con
             } else {
                 win = *(const f32x4 *)(rec + (long)win_idx * 8);
             }
-            if (tid == 0) s_kept[kept] = win_idx;                // written out once below (see nms_block_kernel)
+            if (tid == 0) s_kept[kept] = win_idx;                // written out once below (see nms_block_tier)
             ++kept;
         }
         if (tid == 0) kept_count[pair] = kept;
@@ -283,11 +283,11 @@ __global__ __launch_bounds__(1024) void nms_bucket_kernel(const float *records, 
 // Same greedy order and suppression predicate as nms_kernel (largest (score, -index) key first, IoU > thr
 // strict), for pairs of at most 64 * kSlots candidates: no LDS, no workgroup barrier, the winner's box
 // travels by v_readlane.  Typical pairs have a handful of candidates, so thousands of pairs run at once.
-__global__ __launch_bounds__(kThreads) void nms_wave_kernel(const float *records, const int *class_count, const int *ws,
-                                                            int ws_stride, int B, int N, int C, int max_boxes, float thr,
-                                                            int *kept_idx, int *kept_rank, int *kept_count) {
+__device__ __forceinline__ void nms_wave_tier(int block, int blocks, const float *records, const int *class_count, const int *ws,
+                                              int ws_stride, int B, int N, int C, int max_boxes, float thr,
+                                              int *kept_idx, int *kept_rank, int *kept_count) {
     const int lane = threadIdx.x & 63;
-    const int wave0 = (blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = (gridDim.x * kThreads) >> 6;
+    const int wave0 = (block * kThreads + (int)threadIdx.x) >> 6, nwaves = (blocks * kThreads) >> 6;
     for (int pair = wave0; pair < B * C; pair += nwaves) {
         const int b = pair / C, c = pair - b * C;
         const int n = __builtin_amdgcn_readfirstlane(class_count[pair]);
@@ -370,14 +370,14 @@ __global__ __launch_bounds__(kThreads) void nms_wave_kernel(const float *records
 // Up to four candidates per thread, in registers.  One barrier per round: every wave publishes its best key
 // AND that candidate's box; after the barrier each thread picks the winning wave's pair from LDS (buffers
 // alternate between rounds).  Same order and predicate as the other two kernels.
-__global__ __launch_bounds__(kThreads) void nms_block_kernel(const float *records, const int *class_count, const int *ws,
-                                                             int ws_stride, int B, int N, int C, int max_boxes, float thr,
-                                                             int *kept_idx, int *kept_rank, int *kept_count) {
+__device__ __forceinline__ void nms_block_tier(int block, int blocks, const float *records, const int *class_count, const int *ws,
+                                               int ws_stride, int B, int N, int C, int max_boxes, float thr,
+                                               int *kept_idx, int *kept_rank, int *kept_count) {
     __shared__ unsigned long long s_key[2][4];
     __shared__ f32x4 s_box[2][4];
     __shared__ int s_kept[kThreads], s_rank[kThreads];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int pair = blockIdx.x; pair < B * C; pair += gridDim.x) {
+    for (int pair = block; pair < B * C; pair += blocks) {
         const int b = pair / C, c = pair - b * C;
         const int n = class_count[pair];
         const int *wsb = ws + (long)b * ws_stride;
@@ -452,6 +452,19 @@ __global__ __launch_bounds__(kThreads) void nms_block_kernel(const float *record
     }
 }
 
+// The two register-resident tiers in ONE launch: workgroups [0, block_blocks) run the workgroup-per-pair tier -- first,
+// because a crowded pair's up to max_boxes sequential rounds are the launch's critical path -- and the others the
+// wavefront-per-pair tier, which fills the chip around them (as two launches their times added: 22 + 120 us).
+__global__ __launch_bounds__(kThreads) void nms_tiers_kernel(const float *records, const int *class_count, const int *ws,
+                                                             int ws_stride, int B, int N, int C, int max_boxes, float thr,
+                                                             int *kept_idx, int *kept_rank, int *kept_count, int block_blocks) {
+    if ((int)blockIdx.x < block_blocks)
+        nms_block_tier((int)blockIdx.x, block_blocks, records, class_count, ws, ws_stride, B, N, C, max_boxes, thr, kept_idx, kept_rank, kept_count);
+    else
+        nms_wave_tier((int)blockIdx.x - block_blocks, (int)gridDim.x - block_blocks, records, class_count, ws, ws_stride, B, N, C, max_boxes, thr,
+                      kept_idx, kept_rank, kept_count);
+}
+
 __global__ __launch_bounds__(kThreads) void pack_kernel(const float *records, const int *kept_idx, const int *kept_count,
                                                         int N, int C, int max_boxes, float *out_boxes,
                                                         float *out_scores, int *out_classes, int *out_count) {
@@ -511,11 +524,8 @@ static int launch_nms(const float *records, const int32_t *cand_idx, const int32
                            boxes_per_image, num_classes, workspace, ws_stride);
         int wblocks = (pairs + 3) / 4;
         if (wblocks > 256 * 8) wblocks = 256 * 8;
-        hipLaunchKernelGGL(nms_wave_kernel, dim3(wblocks), dim3(kThreads), 0, stream, records, class_count, workspace, ws_stride,
-                           batch, boxes_per_image, num_classes, max_boxes, iou_threshold, kept_idx, kept_rank, kept_count);
-        hipLaunchKernelGGL(nms_block_kernel, dim3(pairs), dim3(kThreads), 0, stream, records, class_count,
-                           workspace, ws_stride, batch, boxes_per_image, num_classes, max_boxes, iou_threshold, kept_idx,
-                           kept_rank, kept_count);
+        hipLaunchKernelGGL(nms_tiers_kernel, dim3(pairs + wblocks), dim3(kThreads), 0, stream, records, class_count, workspace, ws_stride,
+                           batch, boxes_per_image, num_classes, max_boxes, iou_threshold, kept_idx, kept_rank, kept_count, pairs);
     }
     const int per_cu = lds > 0 ? (155 * 1024) / (lds + 1024) : 8;
     int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
