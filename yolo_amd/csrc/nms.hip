@@ -468,26 +468,34 @@ __global__ __launch_bounds__(kThreads) void nms_tiers_kernel(const float *record
 __global__ __launch_bounds__(kThreads) void pack_kernel(const float *records, const int *kept_idx, const int *kept_count,
                                                         int N, int C, int max_boxes, float *out_boxes,
                                                         float *out_scores, int *out_classes, int *out_count) {
-    __shared__ int s_off[128];
+    __shared__ int s_n[128], s_off[128];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) {
+    if (tid < C) s_n[tid] = min(kept_count[b * C + tid], max_boxes);       // (C <= 127: checked by the caller)
+    __syncthreads();
+    if (tid <= C) {                                                    // exclusive prefix, every thread its own (C is small)
         int acc = 0;
-        for (int c = 0; c < C; ++c) { s_off[c] = acc; acc += min(kept_count[b * C + c], max_boxes); }
-        s_off[C] = acc;
-        out_count[b] = acc;
+        for (int c = 0; c < tid; ++c) acc += s_n[c];
+        s_off[tid] = acc;
+        if (tid == C) out_count[b] = acc;
     }
     __syncthreads();
     const long cap = (long)C * max_boxes;
     const float *rec = records + (long)b * N * 8;
-    for (int c = 0; c < C; ++c) {                                  // class-major, inference.py:163-165
-        const int cnt = s_off[c + 1] - s_off[c];
-        for (int k = tid; k < cnt; k += kThreads) {
-            const int idx = kept_idx[((long)b * C + c) * max_boxes + k];
-            const long o = b * cap + s_off[c] + k;
-            *(f32x4 *)(out_boxes + o * 4) = *(const f32x4 *)(rec + (long)idx * 8);
-            out_scores[o] = rec[(long)idx * 8 + 4];
-            out_classes[o] = c;
+    // class-major, inference.py:163-165: output slot i belongs to the class whose offset range holds it (binary search in
+    // the LDS prefix table; one pass over the image's <= C * max_boxes detections instead of one short pass per class)
+    const int total = s_off[C];
+    for (int i = tid; i < total; i += kThreads) {
+        int lo = 0, hi = C;                                        // s_off[lo] <= i < s_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= i) lo = mid; else hi = mid;
         }
+        const int c = lo, k = i - s_off[c];
+        const int idx = kept_idx[((long)b * C + c) * max_boxes + k];
+        const long o = b * cap + i;
+        *(f32x4 *)(out_boxes + o * 4) = *(const f32x4 *)(rec + (long)idx * 8);
+        out_scores[o] = rec[(long)idx * 8 + 4];
+        out_classes[o] = c;
     }
 }
 
