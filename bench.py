@@ -89,8 +89,29 @@ def cpu_baseline(model_cfg, size, n_images, score_threshold):
                       % (n_images, size, size)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started without a launcher: start N fresh child ranks under torch.distributed.run
+    (one process per GPU, RCCL), relay rank 0's JSON line and exit with the launcher's code.  This process never
+    touches a GPU (torch.cuda.device_count() does not initialise one), and nothing is re-executed in place."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("YOLO_AMD_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if not rehearsal and have < n:
+        sys.exit("bench.py: --gpus %d but only %d GPU(s) visible" % (n, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -105,7 +126,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # one process per GPU: this rank's kernels, arena and events all live on its own device (checked before any launch)

@@ -122,7 +122,10 @@ int y3_conv_stem(const y3_stem_desc *desc, const float *image, const float *w0, 
  * against y3_conv2d_fused(1x1), which adds the same products in channel order, about one output in 10^4 differs by one
  * bf16 ulp), so a host may move that 1x1 between the two launches freely.  flags: 1 = leaky-ReLU after the 1x1,
  * 2 = after the 3x3, Y3_CONV_REVERSE = scheduling hint.  y3_resblock_tiles (host only) says whether a shape is
- * supported (Y3_OK) and how many workgroup tiles it has, so that a planner can decide when fusing pays. */
+ * supported (Y3_OK) and how many workgroup tiles it has, so that a planner can decide when fusing pays.
+ * x and out must not overlap (a tile reads its neighbours' halo pixels of x): overlapping ranges are refused with
+ * Y3_E_INVALID.  y3_conv2d_fused, by contrast, allows residual == out (each element is loaded before it is stored, by
+ * the same lane). */
 typedef struct y3_resblock_desc {
     int32_t dtype;        /* Y3_BF16                                                                  */
     int32_t batch, h, w;  /* NHWC activations, same size in and out                                    */

@@ -364,7 +364,8 @@ def test_head_decode_fused_into_the_head_convolutions(size, batch, chunk, thr):
     net.set_params(dw.random_params(layers, seed=21))
     anchors = inference.read_anchors(config.anchors_path)
     x = torch.rand((batch, size, size, 3), dtype=torch.float32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(size + batch))
-    shapes = np.stack([np.array([300 + 7 * i, 500 - 5 * i]) for i in range(batch)])
+    shapes = np.stack([np.array([300 + 7 * i, 500 - 3 * i]) for i in range(batch)])      # every image has a positive size
+    assert shapes.min() > 0
     plain = PostProcessor(anchors, 80, (size, size), thr, 0.3, 51)
     heads = net.forward(x, chunk=chunk)
     want = plain(heads, shapes)
@@ -388,9 +389,20 @@ def test_head_decode_fused_into_the_head_convolutions(size, batch, chunk, thr):
         for i, m in enumerate(w_out[3].cpu().numpy()):             # (the padded tails are uninitialised memory)
             for g, w in zip((got.boxes, got.scores, got.classes), w_out[:3]):
                 torch.testing.assert_close(g[i, :m], w[i, :m], rtol=0, atol=0)
+        # the bench path's OWN output against the oracle (not only against its un-fused twin): NMS + pack of detect()'s
+        # records equal the oracle's select() on the same decoded boxes, bit for bit ...
+        for b in sorted({0, batch // 2, batch - 1}):
+            _check_nms_exact(got, b, thr)
         if want_heads:
             for g, w in zip(gh, heads):
                 torch.testing.assert_close(g, w, rtol=0, atol=0)
+            # ... and its records of image 0 equal the oracle's decode (utils/utils.py:43-160) of the head values
+            # the same launch wrote (fp32 arithmetic: boxes rtol 1e-5, scores 2e-6 as in tests/test_gpu_decode.py)
+            ob, osc = odec.pooled_boxes_and_scores([g[:1, ..., :255].cpu().numpy() for g in gh], anchors, 80, (size, size),
+                                                   tuple(int(v) for v in shapes[0]))
+            rec0 = got.records[0].cpu().numpy()
+            np.testing.assert_allclose(rec0[:, :4], ob, rtol=1e-5, atol=1e-3)
+            np.testing.assert_allclose(rec0[:, 4], osc.max(axis=1), rtol=0, atol=2e-6)
         else:
             assert gh is None
     assert int(w_out[3].sum()) > 0
@@ -419,8 +431,11 @@ def test_frozen_graph_named_nodes():
     nodes = [g.get_tensor_by_name("scale_%d:0" % k) for k in (1, 2, 3)]
     got = [t.clone() for t in g.run(nodes, {g.get_tensor_by_name("input_image:0"): x, "input_shape:0": (96, 96)})]
     want = net(torch.from_numpy(x))
-    for a, b in zip(got, want):
+    layers, oi = od.parse_layers(cfg, 80)
+    ref = od.forward(layers, oi, dw.random_params(layers, seed=11), x)           # the oracle, not the shim's own back end
+    for a, b, r in zip(got, want, ref):
         assert a.shape == b.shape and torch.equal(a[..., :255], b[..., :255])
+        assert tuple(a[..., :255].shape) == r.shape and np.abs(a[..., :255].cpu().numpy() - r).max() <= 1e-3
     assert [t.shape[1] for t in got] == [3, 6, 12]
     one = g.run("scale_2:0", {"input_image:0": x[0]})              # [S,S,3] gets its batch dimension
     assert torch.equal(one[..., :255], want[1][..., :255])

@@ -169,6 +169,22 @@ def test_decode_known_answers():
         assert s == np.float32(lb["scale"]) and [oh, ow] == lb["offset_hw"], lb["name"]
 
 
+def test_product_letterbox_params_known_answers_and_bad_shapes():
+    """yolo_amd.postprocess.letterbox_params (host side of correct_boxes, utils/utils.py:111-116): the golden
+    known answers, and a ValueError for an image without a positive height and width (the reference would divide by
+    it and hand back inf / NaN boxes)."""
+    from yolo_amd.postprocess import letterbox_params
+    gold = json.load(open(os.path.join(GOLD, "decode_cases.json")))
+    for lb in gold["letterbox"]:
+        s, oh, ow = letterbox_params(tuple(lb["input_shape"]), tuple(lb["image_shape"]))
+        assert s == np.float32(lb["scale"]) and [oh, ow] == lb["offset_hw"], lb["name"]
+    for bad in ((0, 500), (300, -95), (-1, -1), (float("nan"), 10), (float("inf"), 10), (5,), (1, 2, 3)):
+        with pytest.raises(ValueError):
+            letterbox_params((608, 608), bad)
+    with pytest.raises(ValueError):
+        letterbox_params((0, 608), (10, 10))
+
+
 def test_decode_only_argmax_class_scores():
     rng = np.random.default_rng(7)
     out = rng.standard_normal((1, 13, 13, 255)).astype(np.float32)

@@ -192,3 +192,72 @@ def test_inplace_shortcuts_alias_the_dead_operand():
     for a, b in zip(plan_sim.Sim(on, layers, params, x).run(), ref):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4)
     assert on.arena_bytes <= off.arena_bytes
+
+
+def test_automatic_mode_fuses_the_64_channel_block_only_behind_the_stem():
+    """resblock64_kernel sums its 1x1 in the stem's k-slot order, so the automatic mode (same bits at every
+    batch size) may fuse the 64-channel block only where the small-batch plan computes that 1x1 in the stem's launch."""
+    layers, oi = planner.parse_cfg(config.yolov3_cfg_path, 80)
+    for kw, want in ((dict(), True), (dict(stem=False), False), (dict(pad_input=True), False)):
+        plan = planner.build_plan(layers, oi, 64, 608, 608, "bf16", **kw)
+        cs = [op["c"] for op in plan.ops if op["kind"] == "resblock"]
+        assert (64 in cs) == want, (kw, cs)
+        assert 128 in cs                                        # the 128-channel blocks do not depend on the stem
+    forced = planner.build_plan(layers, oi, 64, 608, 608, "bf16", stem=False, resblock=True)
+    assert 64 in [op["c"] for op in forced.ops if op["kind"] == "resblock"]      # resblock=True: the caller's choice
+
+
+ALIAS_CFG = """[net]
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+[route]
+layers=-1
+[convolutional]
+batch_normalize=1
+filters=16
+size=1
+stride=1
+pad=1
+activation=leaky
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+[shortcut]
+from=-4
+activation=linear
+[route]
+layers=1
+[convolutional]
+filters=8
+size=1
+stride=1
+pad=1
+activation=linear
+"""
+
+
+def test_inplace_shortcut_sees_readers_through_route_aliases(tmp_path):
+    """a single-input route shares its source's storage; a layer that reads the shortcut operand through
+    such an alias AFTER the sum is written must keep the sum out of the operand's storage."""
+    path = tmp_path / "yolov3.cfg"
+    path.write_text(ALIAS_CFG)
+    layers, oi = planner.parse_cfg(str(path), 80)
+    ol, ooi = od.parse_layers(str(path), 80)
+    params = dw.random_params(layers, seed=5)
+    x = np.random.default_rng(5).random((1, 16, 16, 3), dtype=np.float32)
+    ref = od.forward(ol, ooi, params, x)
+    plan = planner.build_plan(layers, oi, 1, 16, 16, "fp32", stem=False, inplace_shortcut=True)
+    sc = [op for op in plan.ops if op.get("res") is not None]
+    assert len(sc) == 1 and sc[0]["res"]["buf"] != sc[0]["y"]["buf"]        # not in place: layer 6 still reads layer 0
+    out = plan_sim.Sim(plan, layers, params, x).run()
+    for a, b in zip(out, ref):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4)

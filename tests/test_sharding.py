@@ -47,3 +47,20 @@ def test_gather_counts_world2_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_bench_refuses_more_ranks_than_visible_gpus():
+    """bench.py --gpus N started plainly spawns N ranks itself (bench.spawn_ranks) -- and fails loudly, before anything
+    touches a GPU, when fewer than N devices are visible (this container has none)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the spawn itself is covered by the gpu tests")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("YOLO_AMD_BENCH_REHEARSAL", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr

@@ -48,3 +48,23 @@ def test_bench_two_ranks_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
     assert "cpu_baseline" not in d                         # rank 0 at N = 1 only
     assert abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-2      # whole-job aggregate
+
+
+def test_bench_plain_start_spawns_its_ranks():
+    """`python bench.py --gpus 2` without a launcher is a real 2-rank run (bench.spawn_ranks starts the ranks under
+    torch.distributed.run before anything touches the GPU), not a silent 1-rank one; and it refuses when fewer GPUs
+    than ranks are visible (outside the rehearsal mode, which puts every rank on device 0)."""
+    env = dict(os.environ, YOLO_AMD_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["distributed"]["world"] == 2 and d["distributed"]["ranks_reporting"] == 2
+    assert d["config"]["global_batch"] == 4
+    env.pop("YOLO_AMD_BENCH_REHEARSAL")
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
+                           capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

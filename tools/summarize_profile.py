@@ -43,6 +43,7 @@ def main():
     fetch = load_counter(os.path.join(root, "pmc_fetch"), "FETCH_SIZE")
     write = load_counter(os.path.join(root, "pmc_write"), "WRITE_SIZE")
     sq = {c: load_counter(os.path.join(root, "pmc_sq"), c) for c in SQ_COUNTERS}
+    l2 = {c: load_counter(os.path.join(root, "pmc_l2"), c) for c in ("TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum")}
     out = {}
     for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"]):
         if s["pct"] < 0.05:
@@ -54,6 +55,16 @@ def main():
             e["write_bytes_per_launch"] = write[k][0] * 1024 / write[k][1]
         if "fetch_bytes_per_launch_corrected" in e and "write_bytes_per_launch" in e:
             e["hbm_bytes_per_launch"] = e["fetch_bytes_per_launch_corrected"] + e["write_bytes_per_launch"]
+        # L2 pass (own run).  TCC_REQ_sum counts the 128-byte requests the CUs send to the XCDs' L2s: for an LDS-DMA-fed
+        # kernel that is its L2 -> LDS staging traffic plus the epilogue's loads and stores (checked on the 256x256
+        # implicit-GEMM tile: 1 444 tiles x 1 180 KB staged + 378 MB of epilogue = 2.08 GB against 16.2 M requests).
+        r = l2["TCC_REQ_sum"].get(k)
+        if r and r[1]:
+            e["l2_request_bytes_per_launch"] = 128.0 * r[0] / r[1]
+            e["l2_request_tbps"] = e["l2_request_bytes_per_launch"] / (s["avg_us"] * 1e-6) / 1e12
+            h, m = l2["TCC_HIT_sum"].get(k), l2["TCC_MISS_sum"].get(k)
+            if h and m and h[0] + m[0] > 0:
+                e["l2_hit_pct"] = 100.0 * h[0] / (h[0] + m[0])
         # SQ pass (own run): MFMA-pipe busy share and where wave time goes.  GRBM_GUI_ACTIVE is summed over the
         # 8 XCDs (MI355X_MICROARCH.md, DVFS give-back), SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs;
         # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_ANY are in quad-cycles and disjoint shares of wave time.

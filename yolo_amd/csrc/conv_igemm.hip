@@ -33,15 +33,11 @@
 // Alternatives: 129 (128x256), 258 (256x128, 8 waves), 130/131 (128x128 ring), debug bit 4 (ring for 256/128).
 // Debug bits (high half of y3_set_conv_tile, Y3_EXPERIMENTS only): 1/8/16/32 timing experiments that skip loads or
 // the epilogue (results are garbage), 2 no interleave, 64 force the LDS epilogue, 128 one workgroup per tile.
-// Compile-time switches, default off because they measured slower: Y3_XPF (cross-tile prefetch),
-// Y3_STORE_AUX / Y3_RES_AUX (cache policy of the epilogue's stores and residual loads).
+// Measured and removed: cross-tile prefetch, non-temporal epilogue stores / residual loads.
 #include "common.h"
 #include "decode_box.h"
 #include <type_traits>
 
-#ifndef Y3_DEC_ABLATE
-#define Y3_DEC_ABLATE 0
-#endif
 
 namespace {
 
@@ -270,19 +266,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
                 const int b = d_b, cell = d_cell;
                 const int gy = fast_div(cell, p.fd_wo), gx = cell - gy * p.Wo;
                 float *tl = Cs + (live ? row : 0) * CS_LD + an * E;
-#if Y3_DEC_ABLATE & 1                              // (timing experiments, A/B builds only: results are garbage)
-                DecodedBox o;
-                o.ymin = o.xmin = o.ymax = o.xmax = tl[0]; o.score = tl[4]; o.m0 = o.m1 = o.m2 = 0u;
-#else
                 const DecodedBox o = y3_decode_box(tl, live, C, gx, gy, hd->stride_x, hd->stride_y, hd->anchor[an][0],
                                                    hd->anchor[an][1], d_scale, d_offh, d_offw);
-#endif
                 const int pbox = hd->scale_base + cell * 3 + an;
                 if (live) {
                     float *r = hd->records + ((long)b * hd->N + pbox) * 8;
                     *(f32x4 *)r = f32x4{o.ymin, o.xmin, o.ymax, o.xmax};
                     *(f32x4 *)(r + 4) = f32x4{o.score, __uint_as_float(o.m0), __uint_as_float(o.m1), __uint_as_float(o.m2)};
-                    if (!(Y3_DEC_ABLATE & 2) && o.score >= hd->thr) {                  // inference.py:127
+                    if (o.score >= hd->thr) {                  // inference.py:127
                         const int slot = b - b_lo;
                         s_list[slot * (EP_ROWS * 3) + atomicAdd(&s_cnt[slot], 1)] = pbox;
                         unsigned mm[3] = {o.m0, o.m1, o.m2};
@@ -319,25 +310,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
 // which the hardware ignores, so there is no branch around them.  All residual loads of the wave's tile are
 // issued before the first is used.
 constexpr int CONV_REG_EPILOGUE = 1 << 26;
-// cache policy of the epilogue's stores / residual loads (buffer instruction aux bits: 1 = sc0, 2 = nt, 16 = sc1)
-#ifndef Y3_STORE_AUX
-#define Y3_STORE_AUX 0
-#endif
-#ifndef Y3_RES_AUX
-#define Y3_RES_AUX 0
-#endif
-#ifndef Y3_PIECE_J0
-#define Y3_PIECE_J0 0     // MFMA groups of a k-step that run before the first LDS-DMA piece is issued (4, 8: +1 % slower)
-#endif
-#ifndef Y3_XPF_MAX_ACC
-#define Y3_XPF_MAX_ACC 64  // largest accumulator tile (registers per lane) that gets the cross-tile prefetch
-#endif
-#ifndef Y3_XPF
-#define Y3_XPF 0          // cross-tile prefetch in the persistent kernels (measured +3..7 % SLOWER on the 128-row tiles: off)
-#endif
-#ifndef Y3_RES_EARLY_16THS
-#define Y3_RES_EARLY_16THS 16
-#endif
 
 // Residual pieces [FROM, TO) of the wave's tile (piece = mi * NI/2 + pair): one 16-byte buffer load each.
 // The main loop's last k-step issues the first RES_EARLY pieces (its loader registers are free by then), so
@@ -356,7 +328,7 @@ __device__ __forceinline__ void conv_residual_load(const ConvArgs &p, u32x4 (&rv
         const int gm = m0 + wm * TM + mi * 16 + frow;
         const bool ok = gm < p.M && nl + pr * 32 < p.Cout8;
         rv[mi][pr] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rs_res, ok ? ((unsigned)gm * (unsigned)p.res_ld + (unsigned)nl) * 2u : OOB, pr * 64, Y3_RES_AUX));
+            rs_res, ok ? ((unsigned)gm * (unsigned)p.res_ld + (unsigned)nl) * 2u : OOB, pr * 64, 0));
     }
 }
 
@@ -413,7 +385,7 @@ __device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&ac
                 const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
                 o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
             }
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, pr * 64, Y3_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, pr * 64, 0);
         }
     }
 }
@@ -506,7 +478,6 @@ void conv_igemm_kernel(const ConvArgs p, const HeadDecode hd) {
     // the MFMAs of the first half of the k-step, and land during the second half.
     constexpr int NP = A_IT + B_IT;
     constexpr int NMF = NI * MI;                 // MFMA groups per 32-deep half step
-    constexpr int J0 = NMF >= 16 ? Y3_PIECE_J0 : 0;
     long toff = 0;
     int tapc = 0;
     auto stage_begin = [&]() {
@@ -538,27 +509,13 @@ void conv_igemm_kernel(const ConvArgs p, const HeadDecode hd) {
         }
     };
 
-    // Cross-tile prefetch (register epilogue only: the other epilogue stages through the pipeline buffers): the
-    // last k-step of a tile sets the loader up for the workgroup's next tile and fetches its first k-step, so
-    // those loads are queued ahead of the epilogue's stores and land under them; the next tile's first k-step
-    // then waits for all but the stores (vmcnt counts in order: the XPF_STORES youngest are the stores).
-    constexpr bool XPF_OK = BF16 && NI % 2 == 0 && Y3_XPF != 0 && MI * NI * 4 <= Y3_XPF_MAX_ACC && WAVES_M * WAVES_N == 4;
-    constexpr int XPF_STORES = MI * (NI / 2);
-    static_assert(XPF_STORES < 64, "vmcnt range");
     int pb = 0;                                  // pipeline buffer the next k-step reads
-    int m0n = 0, n0n = 0;                        // tile the loader is set up for
-    bool primed = false;                         // ... and whose first k-step is already in flight
-    bool counted = false;                        // the next k-step waits with vmcnt(XPF_STORES)
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
-    // (after a cross-tile prefetch the set-up is simply recomputed: keeping it in registers through the epilogue
-    // would cost the big tiles ~40 registers they do not have)
-    tile_setup(tile, m0n, n0n);
+    int m0, n0;
+    tile_setup(tile, m0, n0);
     stage_begin();
-    if (!primed) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) piece(q, kt0, pb);     // free: every wave is past the barrier of the last k-step
-    }
-    const int m0 = m0n, n0 = n0n;
+    for (int q = 0; q < NP; ++q) piece(q, kt0, pb);         // free: every wave is past the barrier of the last k-step
 
     // ---- main loop ------------------------------------------------------------------------
     const bool reg_epi = BF16 && (p.flags & CONV_REG_EPILOGUE);     // then the bias is the accumulators' initial value
@@ -578,7 +535,7 @@ void conv_igemm_kernel(const ConvArgs p, const HeadDecode hd) {
     const int nk = p.splits > 1 ? min(nk_all, kt0 + p.nk_split) : nk_all;     // one past this workgroup's last k-step
 
     // residual pieces the last k-step fetches ahead of the epilogue (register epilogue only)
-    constexpr int RES_EARLY = (BF16 && NI % 2 == 0 && MI * NI * 4 <= 96) ? (MI * (NI / 2) * Y3_RES_EARLY_16THS) / 16 : 0;
+    constexpr int RES_EARLY = (BF16 && NI % 2 == 0 && MI * NI * 4 <= 96) ? MI * (NI / 2) : 0;
     using frag_t = typename std::conditional<BF16, bf16x8, f32x4>::type;
     auto mfma_group = [&](int j, const frag_t (&xq)[MI], const frag_t (&wq)[NI]) {
         const int ni = j / MI, mi = j % MI;
@@ -591,12 +548,10 @@ void conv_igemm_kernel(const ConvArgs p, const HeadDecode hd) {
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[ni][i], xq[mi][i], acc[ni][mi], 0, 0, 0);
         }
     };
-    // piece q of the next k-step goes before MFMA group J0 + floor(q * NJ / NP), NJ = NMF - J0: the first J0 groups carry
-    // no piece (and no scheduling barrier), so that they can start while the later fragment reads are still in flight
+    // piece q of the next k-step goes before MFMA group floor(q * NMF / NP) of the first half-step
     auto pieces_before = [&](int j, int kt) {
-        constexpr int NJ = NMF - J0;
 #pragma unroll
-        for (int q = j < J0 ? NP : ((j - J0) * NP + NJ - 1) / NJ; q < ((j - J0 + 1) * NP + NJ - 1) / NJ; ++q) {
+        for (int q = (j * NP + NMF - 1) / NMF; q < ((j + 1) * NP + NMF - 1) / NMF; ++q) {
             if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             piece(q, kt + 1, pb ^ 1);
             if constexpr (INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
@@ -604,10 +559,7 @@ void conv_igemm_kernel(const ConvArgs p, const HeadDecode hd) {
     };
     auto kstep = [&](int kt, auto prefetch, auto early) {
         constexpr bool PF = decltype(prefetch)::value;
-        // this wave's LDS-DMA of k-step kt has landed (after a cross-tile prefetch the epilogue's stores may remain)
-        if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPF_STORES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        counted = false;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of k-step kt has landed
         __syncthreads();                                    // everyone's has; the other buffer is free
         early();
         if constexpr (PF) stage_begin();
@@ -643,18 +595,7 @@ void conv_igemm_kernel(const ConvArgs p, const HeadDecode hd) {
         }
     };
     for (int kt = kt0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{}, [] {});
-    const int next_tile = tile + (int)gridDim.x;
-    primed = XPF_OK && reg_epi && p.splits <= 1 && next_tile < p.total_tiles && !(p.flags & ((1 << 27) | (1 << 25)));
-    if (primed) {
-        kstep(-1, std::true_type{}, [&] {        // "k-step kt + 1" of the prefetch = k-step 0 of the next tile
-            res_early();
-            int m0x, n0x;
-            tile_setup(next_tile, m0x, n0x);
-        });
-        counted = true;
-    } else {
-        kstep(nk - 1, std::false_type{}, res_early);
-    }
+    kstep(nk - 1, std::false_type{}, res_early);
 
 #ifdef Y3_EXPERIMENTS
     if (p.flags & (1 << 27)) {          // timing experiment: no epilogue (one store keeps the accumulators live)
@@ -1220,7 +1161,6 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
     if (g_conv_debug & 8) a.flags |= 1 << 29;  // timing experiment: no A loads at all (garbage results)
     if (g_conv_debug & 16) a.flags |= 1 << 28; // timing experiment: no B loads at all (garbage results)
     if (g_conv_debug & 32) a.flags |= 1 << 27; // timing experiment: no epilogue (no results)
-    if (g_conv_debug & 256) a.flags |= 1 << 25; // experiment: no cross-tile prefetch
 #endif
     const int bke = bf16 ? 64 : 32;
     a.n_tiles = 0;

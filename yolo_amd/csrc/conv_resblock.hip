@@ -34,9 +34,6 @@
 #ifndef Y3_RB_PREFETCH
 #define Y3_RB_PREFETCH 1    // touch the next tile's x and this tile's shortcut lines during phase 2 (L2 prefetch)
 #endif
-#ifndef Y3_RB_ABLATE
-#define Y3_RB_ABLATE 0      // timing experiments (A/B builds only, results are garbage): 1 no phase 1, 2 no phase 2, 4 no epilogue
-#endif
 
 #ifndef Y3_RB_STAMPS
 #define Y3_RB_STAMPS 0      // diagnostic build only (gpurun_ab): per-segment s_memtime sums of every workgroup's wave 0
@@ -225,7 +222,7 @@ void resblock_kernel(const ResArgs p) {
                         }
                     }
                     const int ni = j / MI1, mi = j % MI1;
-                    if constexpr (!(Y3_RB_ABLATE & 1))
+                    
                         acc1[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * kt + ks][ni], xf[mi], acc1[ni][mi], 0, 0, 0);
                 }
             }
@@ -352,7 +349,7 @@ void resblock_kernel(const ResArgs p) {
                 }
             }
         };
-        if constexpr (!(Y3_RB_ABLATE & 2)) {
+        {
             for (int kt = 0; kt + 1 < NK2; ++kt) kstep2(kt, std::true_type{});
         }
         kstep2(NK2 - 1, std::false_type{});
@@ -417,19 +414,12 @@ void resblock_kernel(const ResArgs p) {
             issue_x(b, h0, w0, th);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(Y3_RB_ABLATE & 4)) {
+        {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int pr = 0; pr < NP2; ++pr)
                     __builtin_amdgcn_raw_buffer_store_b128(o[mi][pr], rs_out, ooff[mi], pr * 64, 0);
-        } else {
-            unsigned sacc = 0;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int pr = 0; pr < NP2; ++pr) sacc += o[mi][pr][0] ^ o[mi][pr][1] ^ o[mi][pr][2] ^ o[mi][pr][3];
-            if (sacc == 0x12345678u) *(unsigned *)p.out = sacc;
         }
         RB_STAMP(6);                               // 6: next x issued, stores issued
     }
@@ -510,6 +500,10 @@ extern "C" int y3_resblock_fused(const y3_resblock_desc *d, const void *x, const
     const long xb = pixels * d->x_ld * 2, ob = pixels * d->out_ld * 2;
     Y3_REQUIRE(xb < 0xffff0000L && ob < 0xffff0000L && tiles < 0x7fffffffL, Y3_E_INVALID,
                "resblock: tensors of %ld / %ld bytes exceed a 4 GiB buffer descriptor", xb, ob);
+    // every tile reads its neighbours' halo pixels of x, so the sum cannot be written over x (unlike y3_conv2d_fused,
+    // whose residual operand may be `out`: same lane, load before store)
+    Y3_REQUIRE((const char *)x + xb <= (const char *)out || (const char *)out + ob <= (const char *)x, Y3_E_INVALID,
+               "resblock: x and out overlap (tiles read their neighbours' pixels of x)");
     if (c == 128) return y3_resblock128_launch(d, x, w1, b1, w2, b2, out, zeros, (hipStream_t)stream);
     if (c == 64) return y3_resblock64_launch(d, x, w1, b1, w2, b2, out, zeros, (hipStream_t)stream);
     ResArgs a;

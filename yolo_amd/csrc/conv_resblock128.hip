@@ -26,27 +26,6 @@
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-#ifndef R1_ABLATE
-#define R1_ABLATE 0         // timing experiments (tools/ab_build.sh builds only, garbage results): 1 no phase 1, 2 no phase 2,
-#endif                      // 4 no next-patch loads, 8 no stores
-
-#ifndef R1_P1_INTERIOR
-#define R1_P1_INTERIOR 0                           // phase 1 skips the in-picture test on tiles whose patch lies inside the picture
-#endif
-#ifndef R1_P2_PIPE
-#define R1_P2_PIPE 1                               // phase 2: fragment reads of the next tap under this tap's MFMAs
-#endif
-#ifndef R1_SPREAD
-#define R1_SPREAD 1                                // loader passes among phase 2's first taps (0: all at the top of the tile)
-#endif
-#ifndef R1_FASTPATH
-#define R1_FASTPATH 0                              // interior tiles: loader offsets from registers (conv_resblock64.hip) -- here the
-                                                   // seven registers do not fit beside 144 of weights: 21 spilled, off
-#endif
-#ifndef R1_PHASE1_PIPE
-#define R1_PHASE1_PIPE 1
-#endif
-
 namespace {
 
 constexpr int R1_TW = 16, R1_TH = 8;               // tile: 8 rows x 16 pixels
@@ -121,26 +100,7 @@ void resblock128_kernel(const R1Args p) {
     };
     // the tile's 10 x 18 x 128 input patch -> LDS: slot s = 18 * pixel + chunk, chunks 16 and 17 are padding (not written)
     constexpr int NPASS = R1_XBUF / (R1_NT * 16);
-#if R1_FASTPATH
-    int rel[NPASS];                                // interior tiles: byte offset of this lane's slot from the patch's first pixel, -1 = none
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int s = tid + R1_NT * i;
-        const int pos = (s * 3641) >> 16, c = s - pos * 18;
-        const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;
-        rel[i] = (pos < R1_NPOS && c < 16) ? (pr * p.W + pc) * p.x_ld * 2 + c * 16 : -1;
-    }
-#endif
     auto issue_x = [&](int b, int h0, int w0, char *buf, int i0 = 0, int i1 = NPASS) {
-#if R1_FASTPATH
-        if (h0 >= 1 && w0 >= 1 && h0 + R1_TH + 1 <= p.H && w0 + R1_TW + 1 <= p.W) {    // (wave-uniform)
-            const char *base = p.x + (long)((b * p.H + h0 - 1) * p.W + w0 - 1) * p.x_ld * 2;
-#pragma unroll
-            for (int i = i0; i < i1; ++i)
-                if (rel[i] >= 0) glds16(base + rel[i], buf + i * (R1_NT * 16) + wave * 1024);
-            return;
-        }
-#endif
         // (the slot -> pixel arithmetic is recomputed per tile on purpose: hoisted out of the tile loop its 7 x 4 values
         // push the kernel past 256 registers and hipcc reloads them from scratch behind vmcnt(0) waits)
         int tidv = tid;
@@ -178,16 +138,13 @@ void resblock128_kernel(const R1Args p) {
         const char *xb = smem + cur * R1_XBUF;
         const int next = tile + (int)gridDim.x;
         int nb = 0, nh0 = 0, nw0 = 0;
-        const bool more = next < p.total_tiles && !(R1_ABLATE & 4);
+        const bool more = next < p.total_tiles;
         if (more) {                                // the next tile's patch travels under this tile's MFMAs
             tile_coords(next, nb, nh0, nw0);
-            if (!R1_SPREAD) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R1_XBUF);
         }
         // ---- phase 1: y = leaky(W1 x + b1) on the patch -----------------------------------------------------------
-        const bool interior = h0 >= 1 && w0 >= 1 && h0 + R1_TH + 1 <= p.H && w0 + R1_TW + 1 <= p.W;   // (wave-uniform)
         int frv = frow;                            // (opaque per tile: keeps phase 1's per-lane addresses out of scratch,
         asm volatile("" : "+v"(frv));              // where hipcc parks them as loop invariants and reloads behind vmcnt(0))
-#if R1_PHASE1_PIPE
         // W1's fragments of this wave's block pair once per tile (32 registers that phase 2's accumulators take over
         // afterwards), the patch fragments of row block j + 1 requested ahead of row block j's MFMAs, and the two
         // 16-channel chains interleaved so that no MFMA waits for the one before it
@@ -201,21 +158,12 @@ void resblock128_kernel(const R1Args p) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + ((wave >> 1) * 16 + frv) * R1_XP + (kb * 4 + fq) * 16);
 #pragma unroll
-            for (int j = 0; j < ((R1_ABLATE & 1) ? 0 : 3); ++j) {
+            for (int j = 0; j < 3; ++j) {
                 const int pos = ((wave + 8 * j) >> 1) * 16 + frv;
-#if R1_PHASE1_PIPE == 2
-                bf16x8 xn[4];
-                if (j < 2) {
-                    const int posn = ((wave + 8 * (j + 1)) >> 1) * 16 + frv;
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) xn[kb] = *(const bf16x8 *)(xb + posn * R1_XP + (kb * 4 + fq) * 16);
-                }
-#elif R1_PHASE1_PIPE == 1
                 if (j > 0) {
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + pos * R1_XP + (kb * 4 + fq) * 16);
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 a1[2] = {bias1(0), bias1(1)};
 #pragma unroll
@@ -223,16 +171,8 @@ void resblock128_kernel(const R1Args p) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) a1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][kb], xf[kb], a1[q], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-#if R1_PHASE1_PIPE == 3
-                if (j < 2) {                       // the next row block's fragments travel under this one's leaky / pack / store
-                    const int posn = ((wave + 8 * (j + 1)) >> 1) * 16 + frv;
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + posn * R1_XP + (kb * 4 + fq) * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#endif
                 bool in = true;                    // outside the picture: the 3x3's zero padding
-                if (!(R1_P1_INTERIOR && interior)) {
+                {
                     const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;
                     const int h = h0 - 1 + pr, w = w0 - 1 + pc;
                     in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
@@ -245,47 +185,8 @@ void resblock128_kernel(const R1Args p) {
                     const unsigned o0 = in ? pack_bf16x2(v[0], v[1]) : 0u, o1 = in ? pack_bf16x2(v[2], v[3]) : 0u;
                     if (pos < R1_NPOS) lds_store8_unordered(ybuf + pos * R1_YP + ((nip * 2 + q) * 16 + fq * 4) * 2, o0, o1);
                 }
-#if R1_PHASE1_PIPE == 2
-                if (j < 2) {
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) xf[kb] = xn[kb];
-                }
-#endif
             }
         }
-#else
-#pragma unroll
-        for (int j = 0; j < ((R1_ABLATE & 1) ? 0 : 3); ++j) {
-            const int blk = (wave + 8 * j) >> 1;   // row block 0..11 of this (row block, block pair) unit
-            const int pos = blk * 16 + frv;
-            f32x4 a1[2] = {bias1(0), bias1(1)};
-            bf16x8 xf[4];                          // fragment reads in two batches of eight and four, each ahead of its MFMAs
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) xf[kb] = *(const bf16x8 *)(xb + pos * R1_XP + (kb * 4 + fq) * 16);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                bf16x8 wa[4];
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-                    wa[kb] = *(const bf16x8 *)(w1buf + ((nip * 2 + q) * 16 + frv) * R1_W1P + (kb * 4 + fq) * 16);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) a1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[kb], xf[kb], a1[q], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const int pr = (pos * 3641) >> 16, pc = pos - pr * R1_PW;
-            const int h = h0 - 1 + pr, w = w0 - 1 + pc;
-            const bool in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;        // outside: the 3x3's zero padding
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                f32x4 v = a1[q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = leaky_max(v[e], slope1);
-                const unsigned o0 = in ? pack_bf16x2(v[0], v[1]) : 0u, o1 = in ? pack_bf16x2(v[2], v[3]) : 0u;
-                if (pos < R1_NPOS) lds_store8_unordered(ybuf + pos * R1_YP + ((nip * 2 + q) * 16 + fq * 4) * 2, o0, o1);
-            }
-        }
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // the y image is complete
         asm volatile("" ::: "memory");
@@ -295,7 +196,6 @@ void resblock128_kernel(const R1Args p) {
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[ni][r] = bias2(ni);
-#if R1_P2_PIPE
         // Software pipeline at half-tap granularity, register-neutral: the four fragments of k-block kb are re-read for the
         // NEXT tap right after this tap's eight MFMAs of that k-block have been issued, so the LDS round trip runs under
         // the other k-block's MFMAs.  (All eight waves leave the barrier together: un-pipelined they all read, then all
@@ -313,7 +213,7 @@ void resblock128_kernel(const R1Args p) {
             };
             rd(0, 0);
             rd(0, 1);
-            constexpr int NT9 = (R1_ABLATE & 2) ? 1 : 9;
+            constexpr int NT9 = 9;
 #pragma unroll
             for (int t = 0; t < NT9; ++t) {
 #pragma unroll
@@ -328,42 +228,12 @@ void resblock128_kernel(const R1Args p) {
                     if (t + 1 < NT9) rd(t + 1, kb);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (R1_SPREAD && t < NPASS) {
+                if (t < NPASS) {
                     if (more) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R1_XBUF, t, t + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-#else
-#pragma unroll
-        for (int t = 0; t < ((R1_ABLATE & 2) ? 1 : 9); ++t) {
-            const int dh = t / 3, dw = t - 3 * dh;
-            // all eight fragment reads of the tap first, then its sixteen MFMAs: left alone, hipcc issues read, wait, two
-            // MFMAs eight times over (72 exposed LDS round trips per tile); hoisting more than one tap's reads instead, with
-            // 144 weight registers live, goes into scratch spills of the weights themselves
-            bf16x8 yf[2][4];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    yf[kb][r] = *(const bf16x8 *)(ybuf + ((4 * wm + r + dh) * R1_PW + dw + frow) * R1_YP + (kb * 4 + fq) * 16);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[ni][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[t][kb][ni], yf[kb][r], acc[ni][r], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // (R1_SPREAD) one loader pass after each of the first taps: an LDS-DMA instruction holds its wave for 60-180
-            // cycles, which the SIMD's other wave fills with MFMAs here and cannot at the top of the tile
-            if (R1_SPREAD && t < NPASS) {
-                if (more) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R1_XBUF, t, t + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#endif
         // ---- epilogue: leaky, pairing, + x (the patch's centre, from LDS) in fp32, one bf16 rounding, 16-byte stores ----
         const int w = w0 + frow;
 #pragma unroll
@@ -392,7 +262,7 @@ void resblock128_kernel(const R1Args p) {
             o[2] = pack_bf16x2(hi[0], hi[1]); o[3] = pack_bf16x2(hi[2], hi[3]);
             const bool ok = h < p.H && w < p.W;
             const unsigned off = ok ? ((unsigned)((b * p.H + h) * p.W + w) * (unsigned)p.out_ld + (unsigned)(32 * wn + cb)) * 2u : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (R1_ABLATE & 8) ? OOB : off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, 0, 0);
         }
         b = nb; h0 = nh0; w0 = nw0;
         cur ^= 1;

@@ -319,6 +319,13 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
     rb_channels = tuple(int(v) for v in rb_env.split(",") if v) if rb_env else None
     resblocks = find_resblocks(layers, inputs, uses, head_of, shapes, batch, dtype, resblock, rb_channels) if fuse else {}
     resblocks = {i3: v for i3, v in resblocks.items() if fused_into.get(v[2]) == i3}     # the shortcut rides the 3x3
+    if resblock is None:
+        # resblock64_kernel sums its 1x1 in conv_stem's k-slot order (csrc/conv_resblock64.hip), which differs from
+        # y3_conv2d_fused's by one bf16 ulp in ~1 of 1e4 outputs.  The automatic mode promises the same bits at every
+        # batch size, so it fuses a 64-channel block only where the small-batch plan computes that 1x1 in the stem's
+        # launch (stem on, no padded input, the block directly behind the stem).  resblock=True fuses regardless.
+        resblocks = {i3: v for i3, v in resblocks.items()
+                     if shapes[inputs[v[0]][0]][2] != 64 or (stem_layers is not None and stem_layers[2] == v[0])}
     rb_internal = {v[0] for v in resblocks.values()}      # 1x1 outputs that never leave LDS: no buffer, no launch
     if stem_layers is not None and stem_layers[2] in rb_internal:
         stem_layers = (stem_layers[0], stem_layers[1], None)                             # the block's launch computes the 1x1
@@ -360,11 +367,19 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
     # tiles read their neighbours' pixels of x (halo).
     inplace = {}
     if fuse and inplace_shortcut:
+        # readers per STORAGE: a single-input route is an alias of its source (tens[j] = dict(tens[src]) below), so
+        # whoever reads the route reads the source's bytes
+        root = list(range(n))
+        for j, Lj in enumerate(layers):
+            if Lj["type"] == "route" and len(Lj["ids"]) == 1 and Lj["ids"][0] >= 0:
+                root[j] = root[Lj["ids"][0]]
         users = [[] for _ in range(n)]
         for j, ins in enumerate(inputs):
+            if root[j] != j:
+                continue                       # the alias itself reads nothing
             for q in ins:
                 if q is not None and q >= 0:
-                    users[q].append(j)
+                    users[root[q]].append(j)
         for i, p in fused_into.items():
             L = layers[i]
             if L["type"] != "shortcut" or p in resblocks:
@@ -374,8 +389,8 @@ def build_plan(layers, out_index, batch, in_h, in_w, dtype="bf16", in_c=3, fuse=
                 continue
             if layers[src]["type"] == "route":
                 continue
-            if src in absorbed or src in rb_internal or inputs[p] == [src]:
-                continue
+            if src in absorbed or src in rb_internal or root[src] != src or any(q >= 0 and root[q] == src for q in inputs[p]):
+                continue                       # (the 3x3 itself reads R, directly or through a route alias: halo reads would race)
             if any(j != i and j >= p for j in users[src]):
                 continue                       # someone reads R after the sum is written (a route to a head branch)
             inplace[i] = src

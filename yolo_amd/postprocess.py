@@ -21,6 +21,11 @@ def letterbox_params(input_shape, image_shape):
     f = np.float32
     inp = np.array(input_shape, dtype=f)
     img = np.array(image_shape, dtype=f)
+    if inp.shape != (2,) or img.shape != (2,) or not (np.all(np.isfinite(img)) and np.all(img > 0) and np.all(inp > 0)):
+        # the reference divides by whatever it is fed (utils/utils.py:114) and returns inf / NaN boxes; an image has
+        # a positive height and width, anything else is a caller's bug
+        raise ValueError("letterbox_params: input_shape %r / image_shape %r must be positive (h, w)"
+                         % (tuple(np.ravel(input_shape)), tuple(np.ravel(image_shape))))
     scale = np.min(inp / img).astype(f)
     new_shape = np.round(img * scale).astype(f)
     off = (inp - new_shape).astype(f)
