@@ -23,7 +23,7 @@ def to_dev(x, dtype):
 
 
 def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=False, out_f32=False, in_f32=False,
-             in_pad=(0, 0), out_pad=(0, 0), splitk=False, info=None, pool=False):
+             in_pad=(0, 0), out_pad=(0, 0), splitk=False, info=None, pool=False, reverse=False):
     """x NHWC fp32 numpy; kernel HWIO; returns the NHWC fp32 numpy output.  in_pad/out_pad =
     (channels before, channels after) embed the tensor in a wider buffer (route slices)."""
     lib = _lib.load()
@@ -57,7 +57,7 @@ def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=Fals
     d.ksize, d.stride, d.k_pad, d.n_pad = ks, stride, k_pad, n_pad
     d.flags = ((_lib.CONV_LEAKY if leaky else 0) | (_lib.CONV_RESIDUAL if residual is not None else 0)
                | (_lib.CONV_UPS2X if ups else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_IN_F32 if in_f32 else 0)
-               | (_lib.CONV_POOL2 if pool else 0))
+               | (_lib.CONV_POOL2 if pool else 0) | (_lib.CONV_REVERSE if reverse else 0))
     es_in = xin.element_size()
     es_out = out.element_size()
     if splitk:          # y3_conv2d_splitk with the workspace its plan asks for (splits == 1: same as y3_conv2d_fused)

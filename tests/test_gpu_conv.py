@@ -302,6 +302,67 @@ def test_conv3x3_c32_kernel_equals_the_implicit_gemm(H, W, res, leaky, pads):
             np.testing.assert_array_equal(gpu_util.run_conv(x, k, b, 1, "bf16", **kw), got)
 
 
+PP_CASES = [
+    # B, H, W, Cin, Cout, ks, stride, residual, leaky, (in_pad, out_pad)
+    (16, 76, 76, 128, 256, 3, 1, True, True, ((0, 0), (0, 0))),       # the 76x76 residual-stage layer: 361 tiles on 256 workgroups
+    (5, 76, 76, 128, 256, 3, 1, False, True, ((128, 0), (0, 128))),   # channel slices of wider buffers (route)
+    (9, 38, 38, 256, 512, 3, 1, True, False, ((0, 0), (0, 0))),       # two channel tiles, linear activation
+    (48, 19, 19, 512, 1024, 3, 1, True, True, ((0, 0), (0, 0))),      # four channel tiles, 72 k-steps, 272 tiles, ragged last pixel tile
+    (6, 76, 76, 128, 256, 3, 2, False, True, ((0, 0), (0, 0))),       # stride 2 (top/left padding only)
+    (7, 52, 52, 1024, 512, 1, 1, False, True, ((0, 0), (0, 0))),      # 1x1, 16 k-steps
+    (12, 40, 24, 256, 256, 1, 1, True, True, ((0, 0), (8, 8))),       # 1x1 with the minimum of 4 k-steps
+    (3, 33, 47, 96, 256, 3, 1, True, True, ((0, 0), (0, 0))),         # Cin = 96: k-steps straddle taps, K padded 864 -> 896
+    (1, 16, 16, 128, 256, 3, 1, True, True, ((0, 0), (0, 0))),        # a single tile
+    (4, 40, 40, 64, 256, 3, 1, True, True, ((0, 0), (0, 0))),         # 9 k-steps (odd): stays on conv_igemm_kernel
+]
+
+
+@pytest.mark.parametrize("case", PP_CASES, ids=str)
+def test_conv_pingpong_kernel_equals_the_implicit_gemm(case):
+    """conv_pp_kernel (csrc/conv_pp.hip: the 256 x 256 bf16 tile with a four-phase, two-wave-group main loop and a
+    loader that runs ahead across k-steps and tiles): against the oracle, and bit for bit against conv_igemm_kernel's
+    256 x 256 and 128 x 128 tiles (same sums in the same order) -- residual, leaky / linear, stride 2, 1x1, channel
+    slices, ragged tiles, one to four channel tiles, workgroups that walk several tiles, both tile orders."""
+    from yolo_amd import _lib
+    B, H, W, C, O, ks, stride, res, leaky, pads = case
+    rng = np.random.default_rng(B * 1000 + H + C)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, W, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((ks, ks, C, O)) * np.sqrt(2.0 / (ks * ks * C))).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    want = _ref(x, k, b, stride, leaky)
+    r = gpu_util.bf16_round(rng.standard_normal(want.shape).astype(np.float32)) if res else None
+    if res:
+        want = want + r
+    kw = dict(leaky=leaky, residual=r, in_pad=pads[0], out_pad=pads[1])
+    outs = {}
+    with _lib.experimental() as exp:
+        for tile in (512, 256, 128):
+            _lib.check(exp.y3_set_conv_tile(tile))
+            outs[tile] = gpu_util.run_conv(x, k, b, stride, "bf16", **kw)
+        _lib.check(exp.y3_set_conv_tile(512))
+        outs["rev"] = gpu_util.run_conv(x, k, b, stride, "bf16", reverse=True, **kw)
+    assert np.all(np.abs(outs[512] - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
+    for key in (256, 128, "rev"):
+        np.testing.assert_array_equal(outs[512], outs[key])
+
+
+def test_conv_pingpong_is_what_the_big_layers_run_on():
+    """y3_conv_kernel_name: the product library sends the 256 x 256-tile launches with a bf16 output to conv_pp_kernel
+    (the fp32 heads keep conv_igemm_kernel's LDS epilogue with the fused decode)."""
+    from yolo_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = _lib.Y3_BF16, 64, 76, 76, 128, 128
+    d.out_h, d.out_w, d.out_c, d.out_ld, d.res_ld, d.ksize, d.stride, d.k_pad, d.n_pad = 76, 76, 256, 256, 256, 3, 1, 1152, 256
+    d.flags = _lib.CONV_LEAKY | _lib.CONV_RESIDUAL
+    name = ctypes.create_string_buffer(96)
+    _lib.check(lib.y3_conv_kernel_name(ctypes.byref(d), name, 96))
+    assert name.value.decode() == "conv_pp_kernel"
+    d.flags = _lib.CONV_OUT_F32
+    _lib.check(lib.y3_conv_kernel_name(ctypes.byref(d), name, 96))
+    assert name.value.decode().startswith("conv_igemm_kernel<true, 256, 256")
+
+
 @pytest.mark.parametrize("B,H,W,leaky,pads", [(3, 304, 304, True, ((0, 0), (0, 0))), (4, 296, 280, True, ((64, 0), (128, 16))),
                                                (3, 306, 304, False, ((0, 0), (0, 0)))])
 def test_conv3x3s2_c64_kernel_equals_the_implicit_gemm(B, H, W, leaky, pads):

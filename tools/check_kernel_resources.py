@@ -27,7 +27,8 @@ def main(path):
         nxt = block.find("remark: Function Name:")
         block = block if nxt < 0 else block[:nxt]
         vals = {k: int(v) for k, v in re.findall(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\d+)", block)}
-        if vals.get("ScratchSize [bytes/lane]", 0) or vals.get("VGPRs Spill", 0) or vals.get("SGPRs Spill", 0):
+        # (SGPRs spilled to VGPR lanes -- v_writelane / v_readlane, ScratchSize 0 -- issue no vector-memory instruction)
+        if vals.get("ScratchSize [bytes/lane]", 0) or vals.get("VGPRs Spill", 0):
             bad.append((name, vals))
     for name, vals in bad:
         sys.stderr.write("check_kernel_resources: %s has scratch / spills %r: its counted vmcnt(N) waits are no longer "

@@ -35,6 +35,7 @@
 // the epilogue (results are garbage), 2 no interleave, 64 force the LDS epilogue, 128 one workgroup per tile.
 // Measured and removed: cross-tile prefetch, non-temporal epilogue stores / residual loads.
 #include "common.h"
+#include "conv_common.h"
 #include "decode_box.h"
 #include <type_traits>
 
@@ -56,45 +57,6 @@ int conv_cus() {
     const int cus = y3_device_cus();
     return g_conv_cus_cap > 0 && g_conv_cus_cap < cus ? g_conv_cus_cap : cus;
 }
-
-struct ConvArgs {
-    const char *in, *w, *res, *zeros;
-    const float *bias;
-    char *out;
-    int H, W, Cin, in_ld;
-    int Ho, Wo, HoWo, Cout8, out_ld, res_ld;
-    int ks, stride, pad, Kpad, M, n_tiles, flags, step_tap, step_cin, sub_tap, sub_cin;
-    FastDiv fd_howo, fd_wo;
-    unsigned out_bytes, res_bytes;     // extents for the buffer descriptors of the register epilogue
-    int total_tiles;
-    int delay_from;                    // persistent workgroups with blockIdx.x >= delay_from start delay_ticks late
-    unsigned delay_ticks;              // in s_memrealtime ticks (100 MHz)
-    int splits, nk_split;              // split-K: a tile's k-steps are dealt to `splits` workgroups, nk_split each
-    long slice_elems;                  // ... which write fp32 partial sums to out + split * slice_elems
-};
-
-// Output row gm -> byte offset of its window's first input element and the 9-bit (1-bit for 1x1)
-// mask of taps that fall inside the image.  Branch-free; the two divisions are multiplications.
-__device__ __forceinline__ void row_setup(const ConvArgs &p, int gm, int es, long &base, unsigned &mask) {
-    const int b = fast_div(gm, p.fd_howo);
-    const int r = gm - b * p.HoWo;
-    const int ho = fast_div(r, p.fd_wo);
-    const int wo = r - ho * p.Wo;
-    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    base = (((long)b * p.H + hi0) * p.W + wi0) * (long)p.in_ld * es;
-    if (p.ks == 1) {
-        mask = ((unsigned)hi0 < (unsigned)p.H && (unsigned)wi0 < (unsigned)p.W) ? 1u : 0u;
-    } else {
-        unsigned vw = 0, m = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) vw |= ((unsigned)(wi0 + k) < (unsigned)p.W ? 1u : 0u) << k;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) m |= ((unsigned)(hi0 + k) < (unsigned)p.H ? vw : 0u) << (3 * k);
-        mask = m;
-    }
-}
-
-constexpr int CONV_NO_BIAS = 1 << 24;    // internal flag: split-K partial sums carry no bias
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global access
 // (s_waitcnt vmcnt(0)): in the decode epilogue that would put the record stores, the candidate stores and a global
@@ -300,95 +262,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x4 (&acc)[NI
     }
 }
 
-
-// Register epilogue (bf16 in, bf16 out, no upsampling): no LDS round trip, no barrier.  The accumulators were
-// initialised with the bias.  A lane holds 4 consecutive channels of one pixel per 16-channel block; pairs of
-// blocks are exchanged between lane rows r, r^1 with v_permlane16_swap so that each lane owns 8 consecutive
-// channels: the residual arrives as one 16-byte load per lane, is added in fp32 before the single bf16
-// rounding, and the result leaves as one 16-byte store (64 contiguous bytes per pixel and instruction).
-// Loads and stores go through buffer descriptors: lanes past the M or Cout edge get an out-of-range offset,
-// which the hardware ignores, so there is no branch around them.  All residual loads of the wave's tile are
-// issued before the first is used.
-constexpr int CONV_REG_EPILOGUE = 1 << 26;
-
-// Residual pieces [FROM, TO) of the wave's tile (piece = mi * NI/2 + pair): one 16-byte buffer load each.
-// The main loop's last k-step issues the first RES_EARLY pieces (its loader registers are free by then), so
-// that they arrive under its MFMAs; the epilogue issues the rest.
-template <int TM, int TN, int MI, int NI, int FROM, int TO>
-__device__ __forceinline__ void conv_residual_load(const ConvArgs &p, u32x4 (&rv)[MI][NI / 2], int m0, int n0, int lane, int wm, int wn) {
-    constexpr int NP2 = NI / 2;
-    const int frow = lane & 15, fq = lane >> 4;
-    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, p.res_bytes, 0x00020000);
-    const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
-    const int nl = n0 + wn * TN + cb;
-    constexpr unsigned OOB = 0xffffff00u;
-#pragma unroll
-    for (int i = FROM; i < TO; ++i) {
-        const int mi = i / NP2, pr = i % NP2;
-        const int gm = m0 + wm * TM + mi * 16 + frow;
-        const bool ok = gm < p.M && nl + pr * 32 < p.Cout8;
-        rv[mi][pr] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rs_res, ok ? ((unsigned)gm * (unsigned)p.res_ld + (unsigned)nl) * 2u : OOB, pr * 64, 0));
-    }
-}
-
-template <int TM, int TN, int MI, int NI, int RES_EARLY>
-__device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&acc)[NI][MI], u32x4 (&rv_early)[MI][NI / 2], int m0, int n0, int lane, int wm, int wn) {
-    static_assert(NI % 2 == 0, "register epilogue pairs 16-channel blocks");
-    constexpr int NP2 = NI / 2;
-    const int frow = lane & 15, fq = lane >> 4;
-    const bool has_res = p.flags & Y3_CONV_RESIDUAL;
-    const float slope = (p.flags & Y3_CONV_LEAKY) ? 0.1f : 1.0f;
-    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, p.out_bytes, 0x00020000);
-    const int cb = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
-    const int nl = n0 + wn * TN + cb;                       // this lane's first channel in pair 0
-    constexpr unsigned OOB = 0xffffff00u;
-    u32x4 rv_own[MI][NP2];
-    u32x4 (&rv)[MI][NP2] = RES_EARLY > 0 ? rv_early : rv_own;   // a caller's array costs the 256x256 kernel 65 spilled registers
-    if (has_res) conv_residual_load<TM, TN, MI, NI, RES_EARLY, MI * NP2>(p, rv, m0, n0, lane, wm, wn);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int gm = m0 + wm * TM + mi * 16 + frow;
-#pragma unroll
-        for (int pr = 0; pr < NP2; ++pr) {
-            const bool ok = gm < p.M && nl + pr * 32 < p.Cout8;
-            const unsigned off = ok ? ((unsigned)gm * (unsigned)p.out_ld + (unsigned)nl) * 2u : OOB;
-            f32x4 x = acc[2 * pr][mi], y = acc[2 * pr + 1][mi];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                x[j] = leaky_max(x[j], slope);
-                y[j] = leaky_max(y[j], slope);
-            }
-            u32x4 o;
-            if (has_res) {
-                float lo[4], hi[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {              // after the swap: lo = channels 0..3, hi = 4..7 of the lane's 8
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[j]), __float_as_uint(y[j]), false, false);
-                    lo[j] = __uint_as_float(sw[0]);
-                    hi[j] = __uint_as_float(sw[1]);
-                }
-                const u32x4 r = rv[mi][pr];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    lo[2 * j] += bf16_to_f32(r[j] & 0xffff);
-                    lo[2 * j + 1] += __uint_as_float(r[j] & 0xffff0000u);
-                    hi[2 * j] += bf16_to_f32(r[2 + j] & 0xffff);
-                    hi[2 * j + 1] += __uint_as_float(r[2 + j] & 0xffff0000u);
-                }
-                o[0] = pack_bf16x2(lo[0], lo[1]); o[1] = pack_bf16x2(lo[2], lo[3]);
-                o[2] = pack_bf16x2(hi[0], hi[1]); o[3] = pack_bf16x2(hi[2], hi[3]);
-            } else {
-                const unsigned x0 = pack_bf16x2(x[0], x[1]), x1 = pack_bf16x2(x[2], x[3]);
-                const unsigned y0 = pack_bf16x2(y[0], y[1]), y1 = pack_bf16x2(y[2], y[3]);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, off, pr * 64, 0);
-        }
-    }
-}
 
 // Waves per SIMD the launcher counts on (workgroups per CU by LDS x waves per workgroup / 4 SIMDs).  Without it
 // the compiler budgets 512 registers for a 4-wave workgroup, and a kernel that drifts past 256 (VGPR + AGPR)
@@ -1047,6 +920,9 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
     return tile;
 }
 
+// which launches of the 256 x 256 tile take conv_pp.hip's main loop (y3_conv_pp_ok has the per-launch conditions)
+inline bool conv_pp_applies(int v) { return (v == 256 && g_conv_tile == 0 && g_conv_debug == 0) || (v == 512 && g_conv_tile == 512); }
+
 inline int bn_for(int out_c) { return out_c > 64 ? 128 : (out_c > 32 ? 64 : 32); }
 
 bool use_direct(const y3_conv_desc *d) {
@@ -1215,6 +1091,11 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
         return v == 256 ? launch_ring<false, 256, 256, 2, 4, 128>(a, d->n_pad, stream)
                         : launch_ring<false, 128, 128, 2, 2, 128>(a, d->n_pad, stream);
     }
+    // the 256 x 256 bf16 tile with the register epilogue runs on the ping-pong main loop (conv_pp.hip): same bits
+    // (y3_set_conv_tile(256) keeps the one-barrier-per-k-step kernel for A/B runs and the tile-equality tests, 512 forces this one)
+    if (bf16 && splits <= 1 && conv_pp_applies(v) && y3_conv_pp_ok(a, d->n_pad))
+        return y3_conv_pp_launch(a, d->n_pad, conv_cus(), g_conv_phase_pct, stream);
+    if (v == 512) v = 256;
     if (bf16) {
         if (v == 257) return launch_ring<true, 256, 128, 2, 2, 128, 3>(a, d->n_pad, stream);
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
@@ -1450,6 +1331,16 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
         return Y3_OK;
     }
     const int v = conv_variant(d, M);
+    if (d->dtype == Y3_BF16 && conv_pp_applies(v) && !(d->flags & (Y3_CONV_OUT_F32 | Y3_CONV_UPS2X)) && d->out_ld > 0) {
+        ConvArgs a{};                                   // what conv_launch would hand to y3_conv_pp_ok
+        a.flags = CONV_REG_EPILOGUE; a.splits = 1; a.Kpad = d->k_pad; a.Cin = d->in_c; a.M = (int)M;
+        a.HoWo = d->out_h * d->out_w; a.H = d->in_h; a.W = d->in_w; a.in_ld = d->in_ld;
+        const long ob = M * (long)d->out_ld * 2, rb = M * (long)d->res_ld * 2;
+        if (ob < 0xffff0000L && rb < 0xffff0000L && y3_conv_pp_ok(a, d->n_pad)) {
+            snprintf(buf, (size_t)len, "conv_pp_kernel");
+            return Y3_OK;
+        }
+    }
     const char *k = (g_conv_debug & 4) && v >= 128 ? "conv_igemm_ring_kernel" : "conv_igemm_kernel";
     if (v == 257) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 128, 2, 2", t);
     else if (v == 129) snprintf(buf, (size_t)len, "%s<%s, 128, 256, 2, 4", k, t);
@@ -1457,7 +1348,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     else if (v == 260) snprintf(buf, (size_t)len, "conv_igemm_kernel<%s, 256, 64, 4, 2", t);
     else if (v == 261) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 64, 2, 2", t);
     else if (v == 130 || v == 131) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 128, 128, 2, 2", t);
-    else if (v == 256) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
+    else if (v == 256 || v == 512) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
     else if (v == 192) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
     else if (v == 128) snprintf(buf, (size_t)len, "%s<%s, 128, 128, 2, 2", k, t);
     else if (v == 64) snprintf(buf, (size_t)len, "%s<%s, 128, 64, 2, 2", k, t);
@@ -1486,7 +1377,7 @@ extern "C" int y3_set_conv_phase(int percent) {
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
-    Y3_REQUIRE(tile == 0 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 64 || tile == 257 || tile == 258 || tile == 260 || tile == 261, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
+    Y3_REQUIRE(tile == 0 || tile == 512 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 64 || tile == 257 || tile == 258 || tile == 260 || tile == 261, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
     g_conv_tile = tile;
     return Y3_OK;
 }
