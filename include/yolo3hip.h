@@ -92,6 +92,19 @@ int y3_conv2d_splitk(const y3_conv_desc *desc, const void *in, const void *w, co
                      const void *residual, void *out, const void *zeros, void *workspace,
                      int64_t workspace_bytes, void *stream);
 
+/* y3_conv2d_fused with a caller-owned workspace.  The 256 x 256-tile kernel (bf16, bf16 output: the 3x3 layers of 128
+ * and more channels, build_model.py:151-178) walks whole tiles on one persistent workgroup per CU, which leaves a
+ * partial last round (1 444 tiles on 256 CUs at 76 x 76, batch 64).  Given `slabs` it deals the k-steps evenly instead
+ * and sums a tile that two workgroups share in order, the second continuing from the first one's fp32 accumulators:
+ * results are bit-identical to y3_conv2d_fused.  y3_conv_workspace_bytes (host only) says how many bytes `slabs` must
+ * hold for a descriptor (0: the launch does not use it; slabs may be NULL then, and always: NULL = y3_conv2d_fused).
+ * `flags`: 1 KiB that is ZERO when the call is issued (e.g. one hipMemsetAsync per forward pass over one such block
+ * per layer) and not shared with a launch that may overlap this one; `slabs` may be shared by launches on one stream.
+ * Both 16-byte aligned. */
+int y3_conv_workspace_bytes(const y3_conv_desc *desc, int64_t *slab_bytes);
+int y3_conv2d_fused_ws(const y3_conv_desc *desc, const void *in, const void *w, const float *bias, const void *residual,
+                       void *out, const void *zeros, void *slabs, int64_t slab_bytes, void *flags, void *stream);
+
 /* Fused network stem, bf16 mode: the first three convolutions of Darknet-53 in one launch, the
  * 32-channel full-resolution tensor between the first two never leaving LDS:
  *   conv A 3x3 s1 3->c0 on the fp32 NHWC image, conv B 3x3 s2 c0->c1, optional conv C 1x1 c1->c2

@@ -23,7 +23,7 @@ def to_dev(x, dtype):
 
 
 def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=False, out_f32=False, in_f32=False,
-             in_pad=(0, 0), out_pad=(0, 0), splitk=False, info=None, pool=False, reverse=False):
+             in_pad=(0, 0), out_pad=(0, 0), splitk=False, info=None, pool=False, reverse=False, ws=False, extra_flags=0):
     """x NHWC fp32 numpy; kernel HWIO; returns the NHWC fp32 numpy output.  in_pad/out_pad =
     (channels before, channels after) embed the tensor in a wider buffer (route slices)."""
     lib = _lib.load()
@@ -57,7 +57,7 @@ def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=Fals
     d.ksize, d.stride, d.k_pad, d.n_pad = ks, stride, k_pad, n_pad
     d.flags = ((_lib.CONV_LEAKY if leaky else 0) | (_lib.CONV_RESIDUAL if residual is not None else 0)
                | (_lib.CONV_UPS2X if ups else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_IN_F32 if in_f32 else 0)
-               | (_lib.CONV_POOL2 if pool else 0) | (_lib.CONV_REVERSE if reverse else 0))
+               | (_lib.CONV_POOL2 if pool else 0) | (_lib.CONV_REVERSE if reverse else 0) | extra_flags)
     es_in = xin.element_size()
     es_out = out.element_size()
     if splitk:          # y3_conv2d_splitk with the workspace its plan asks for (splits == 1: same as y3_conv2d_fused)
@@ -69,6 +69,21 @@ def run_conv(x, kernel, bias, stride, dtype, leaky=True, residual=None, ups=Fals
         rc = lib.y3_conv2d_splitk(ctypes.byref(d), xin.data_ptr() + in_pad[0] * es_in, wt.data_ptr(), bt.data_ptr(),
                                   res_t.data_ptr() if res_t is not None else None,
                                   out.data_ptr() + out_pad[0] * es_out, zeros.data_ptr(), ws.data_ptr(), ws.numel(), stream())
+    elif ws:            # y3_conv2d_fused_ws with the workspace it asks for: poisoned slabs, zeroed flags
+        nbytes = ctypes.c_int64(0)
+        _lib.check(lib.y3_conv_workspace_bytes(ctypes.byref(d), ctypes.byref(nbytes)))
+        if info is not None:
+            info["slab_bytes"] = int(nbytes.value)
+        slabs = torch.full((max(int(nbytes.value), 16),), 0xff, dtype=torch.uint8, device="cuda")
+        flags = torch.zeros(256, dtype=torch.int32, device="cuda")
+        rc = lib.y3_conv2d_fused_ws(ctypes.byref(d), xin.data_ptr() + in_pad[0] * es_in, wt.data_ptr(), bt.data_ptr(),
+                                    res_t.data_ptr() if res_t is not None else None,
+                                    out.data_ptr() + out_pad[0] * es_out, zeros.data_ptr(), slabs.data_ptr(), slabs.numel(),
+                                    flags.data_ptr(), stream())
+        if info is not None:
+            _lib.check(rc)
+            torch.cuda.synchronize()
+            info["flags_raised"] = int((flags != 0).sum().item())
     else:
         rc = lib.y3_conv2d_fused(ctypes.byref(d), xin.data_ptr() + in_pad[0] * es_in, wt.data_ptr(), bt.data_ptr(),
                                  res_t.data_ptr() if res_t is not None else None,

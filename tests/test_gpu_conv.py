@@ -314,6 +314,8 @@ PP_CASES = [
     (3, 33, 47, 96, 256, 3, 1, True, True, ((0, 0), (0, 0))),         # Cin = 96: k-steps straddle taps, K padded 864 -> 896
     (1, 16, 16, 128, 256, 3, 1, True, True, ((0, 0), (0, 0))),        # a single tile
     (4, 40, 40, 64, 256, 3, 1, True, True, ((0, 0), (0, 0))),         # 9 k-steps (odd): stays on conv_igemm_kernel
+    (32, 38, 38, 256, 512, 3, 1, True, True, ((0, 0), (0, 0))),       # 362 tiles: the balanced split cuts tiles of two channel tiles
+    (64, 19, 19, 512, 1024, 3, 1, False, True, ((0, 0), (0, 0))),     # 364 tiles, 1.4 per workgroup: head + tail and nothing between
 ]
 
 
@@ -341,9 +343,19 @@ def test_conv_pingpong_kernel_equals_the_implicit_gemm(case):
             outs[tile] = gpu_util.run_conv(x, k, b, stride, "bf16", **kw)
         _lib.check(exp.y3_set_conv_tile(512))
         outs["rev"] = gpu_util.run_conv(x, k, b, stride, "bf16", reverse=True, **kw)
+        # y3_conv2d_fused_ws: with a workspace the k-steps are dealt evenly and a tile cut between two workgroups is summed
+        # in order (head by one, tail by the other from the first one's fp32 accumulators): same bits, both tile orders,
+        # and also when every tail gives up on its predecessor and recomputes the head itself (test hook, flag bit 30)
+        info = {}
+        outs["ws"] = gpu_util.run_conv(x, k, b, stride, "bf16", ws=True, info=info, **kw)
+        outs["ws_rev"] = gpu_util.run_conv(x, k, b, stride, "bf16", ws=True, reverse=True, **kw)
+        outs["ws_recompute"] = gpu_util.run_conv(x, k, b, stride, "bf16", ws=True, extra_flags=1 << 30, **kw)
+    tiles = -(-(B * want.shape[1] * want.shape[2]) // 256) * (-(-O // 256))
+    cut = tiles > 256 and tiles % 256 != 0 and C * ks * ks % 128 == 0
+    assert (info["slab_bytes"] > 0) == cut and (info["flags_raised"] > 100) == cut, (tiles, info)
     assert np.all(np.abs(outs[512] - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
-    for key in (256, 128, "rev"):
-        np.testing.assert_array_equal(outs[512], outs[key])
+    for key in (256, 128, "rev", "ws", "ws_rev", "ws_recompute"):
+        np.testing.assert_array_equal(outs[512], outs[key], err_msg=str(key))
 
 
 def test_conv_pingpong_is_what_the_big_layers_run_on():

@@ -41,6 +41,8 @@ class DecodeDesc(ctypes.Structure):
 SIGNATURES = {
     "y3_conv_weight_layout": (c_int, [ctypes.POINTER(ConvDesc)]),
     "y3_conv2d_fused": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "y3_conv_workspace_bytes": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_int64)]),
+    "y3_conv2d_fused_ws": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, c_vp, c_vp]),
     "y3_conv_splitk_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]),
     "y3_conv2d_splitk": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int64, c_vp]),
     "y3_conv_stem": (c_int, [ctypes.POINTER(StemDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -13,6 +13,8 @@ struct ConvArgs {
     FastDiv fd_howo, fd_wo;
     unsigned out_bytes, res_bytes;     // extents for the buffer descriptors of the register epilogue
     unsigned in_bytes, w_bytes;        // ... and of conv_pp_kernel's LDS-DMA loader
+    char *sk_slabs;                    // conv_pp_kernel's balanced split: one 256 KB fp32 slab per workgroup, or null (whole tiles)
+    unsigned *sk_flags;                // ... one flag per workgroup, zero at launch
     int total_tiles;
     int delay_from;                    // persistent workgroups with blockIdx.x >= delay_from start delay_ticks late
     unsigned delay_ticks;              // in s_memrealtime ticks (100 MHz)
@@ -143,3 +145,4 @@ __device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&ac
 // conv_igemm.hip's launcher dispatches to it (same packed weights, same sums in the same order: same bits)
 bool y3_conv_pp_ok(const ConvArgs &a, int n_pad);
 int y3_conv_pp_launch(ConvArgs a, int n_pad, long cus, int phase_pct, hipStream_t stream);
+long y3_conv_pp_slab_bytes(const ConvArgs &a, int n_pad, long cus);      // workspace the balanced split wants (0 = none)

@@ -955,7 +955,7 @@ extern "C" int y3_conv_weight_layout(y3_conv_desc *d) {
 // shortcut or upsampling: conv_splitk_finish_kernel applies those once).
 static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, const float *bias,
                        const void *residual, void *out, const void *zeros, hipStream_t stream, float *workspace, int splits,
-                       const HeadDecode *hd = nullptr) {
+                       const HeadDecode *hd = nullptr, void *pp_slabs = nullptr, long pp_slab_bytes = 0, unsigned *pp_flags = nullptr) {
     Y3_REQUIRE(d && in && w && bias && out && zeros, Y3_E_INVALID, "conv: null pointer argument");
     y3_conv_desc chk = *d;
     const int family = y3_conv_weight_layout(&chk);
@@ -1093,8 +1093,17 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
     }
     // the 256 x 256 bf16 tile with the register epilogue runs on the ping-pong main loop (conv_pp.hip): same bits
     // (y3_set_conv_tile(256) keeps the one-barrier-per-k-step kernel for A/B runs and the tile-equality tests, 512 forces this one)
-    if (bf16 && splits <= 1 && conv_pp_applies(v) && y3_conv_pp_ok(a, d->n_pad))
+    if (bf16 && splits <= 1 && conv_pp_applies(v) && y3_conv_pp_ok(a, d->n_pad)) {
+        a.sk_slabs = nullptr;
+        a.sk_flags = nullptr;
+        if (pp_slabs != nullptr) {                  // the caller's workspace for the balanced split (y3_conv2d_fused_ws)
+            const long need = y3_conv_pp_slab_bytes(a, d->n_pad, conv_cus());
+            Y3_REQUIRE(pp_slab_bytes >= need, Y3_E_INVALID, "conv_ws: workspace of %ld bytes, %ld needed", pp_slab_bytes, need);
+            Y3_REQUIRE(pp_flags != nullptr && aligned16(pp_slabs) && aligned16(pp_flags), Y3_E_ALIGN, "conv_ws: workspace / flags null or not 16-byte aligned");
+            if (need > 0) { a.sk_slabs = (char *)pp_slabs; a.sk_flags = pp_flags; }
+        }
         return y3_conv_pp_launch(a, d->n_pad, conv_cus(), g_conv_phase_pct, stream);
+    }
     if (v == 512) v = 256;
     if (bf16) {
         if (v == 257) return launch_ring<true, 256, 128, 2, 2, 128, 3>(a, d->n_pad, stream);
@@ -1121,6 +1130,32 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
 extern "C" int y3_conv2d_fused(const y3_conv_desc *d, const void *in, const void *w, const float *bias,
                                const void *residual, void *out, const void *zeros, void *stream) {
     return conv_launch(d, in, w, bias, residual, out, zeros, (hipStream_t)stream, nullptr, 1);
+}
+
+// ---- the same convolution with a caller-owned workspace for conv_pp_kernel's balanced split ------------------------
+// Whole 256 x 256 tiles on 256 persistent workgroups leave a partial last round (5.64 -> 6 at 76 x 76, batch 64; 1.42 -> 2
+// at 19 x 19).  With a workspace the k-steps of an XCD group's tiles are dealt evenly instead, a cut tile's head and tail
+// summed in order by two workgroups through an fp32 slab (conv_pp.hip): same bits, no partial round.
+extern "C" int y3_conv_workspace_bytes(const y3_conv_desc *d, int64_t *slab_bytes) {
+    Y3_REQUIRE(d && slab_bytes, Y3_E_INVALID, "conv_workspace_bytes: null pointer argument");
+    *slab_bytes = 0;
+    y3_conv_desc chk = *d;
+    if (y3_conv_weight_layout(&chk) != 0 || chk.n_pad != d->n_pad || chk.k_pad != d->k_pad) return Y3_OK;
+    if (d->dtype != Y3_BF16 || (d->flags & (Y3_CONV_OUT_F32 | Y3_CONV_UPS2X)) || d->out_h <= 0 || d->out_w <= 0) return Y3_OK;
+    const long M = (long)d->batch * d->out_h * d->out_w;
+    if (M >= 0x7fffffffL || !conv_pp_applies(conv_variant(d, M))) return Y3_OK;
+    ConvArgs a{};
+    a.flags = CONV_REG_EPILOGUE; a.splits = 1; a.Kpad = d->k_pad; a.Cin = d->in_c; a.M = (int)M;
+    a.HoWo = d->out_h * d->out_w; a.H = d->in_h; a.W = d->in_w; a.in_ld = d->in_ld;
+    const long ob = M * (long)d->out_ld * 2, rb = M * (long)d->res_ld * 2;
+    if (ob < 0xffff0000L && rb < 0xffff0000L && y3_conv_pp_ok(a, d->n_pad)) *slab_bytes = y3_conv_pp_slab_bytes(a, d->n_pad, conv_cus());
+    return Y3_OK;
+}
+
+extern "C" int y3_conv2d_fused_ws(const y3_conv_desc *d, const void *in, const void *w, const float *bias, const void *residual,
+                                  void *out, const void *zeros, void *slabs, int64_t slab_bytes, void *flags, void *stream) {
+    return conv_launch(d, in, w, bias, residual, out, zeros, (hipStream_t)stream, nullptr, 1, nullptr, slabs, (long)slab_bytes,
+                       (unsigned *)flags);
 }
 
 // ---- a head convolution with the YOLO decode of its scale in the epilogue -----------------------------------------

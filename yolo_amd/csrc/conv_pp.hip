@@ -32,28 +32,42 @@
 
 namespace {
 
-// LDS: X rows of k-step buffer 0 | X rows of buffer 1 | W rows of buffer 0 | W rows of buffer 1 | bias.  With the two
-// buffers of an operand 32 KB apart every fragment read is one per-lane base register + a 16-bit immediate.
+// LDS: X rows of k-step buffer 0 | X rows of buffer 1 | W rows of buffer 0 | W rows of buffer 1 | bias | hand-off word.
+// With the two buffers of an operand 32 KB apart every fragment read is one per-lane base register + a 16-bit immediate.
 constexpr int PP_XBUF = 32 * 1024;                  // 256 rows of 128 bytes
 constexpr int PP_W0 = 2 * PP_XBUF;
 constexpr int PP_BIAS = 4 * PP_XBUF;                // fp32 bias of every output channel of the layer
 constexpr int PP_MAX_COUT = 2048;
-constexpr int PP_LDS = PP_BIAS + PP_MAX_COUT * 4;
+constexpr int PP_DEC = PP_BIAS + PP_MAX_COUT * 4;   // balanced split: 1 = the predecessor's partial sums are there, 2 = recompute
+constexpr int PP_LDS = PP_DEC + 16;
+constexpr int PP_SLAB = 256 * 256 * 4;              // bytes of one workgroup's fp32 partial sums (balanced split)
+constexpr int PP_SPIN_LIMIT = 1 << 17;              // polls of the predecessor's flag before giving up and recomputing
 
-#ifndef PP_PRIO
-#define PP_PRIO 0       // s_setprio 1 around the MFMA clusters (1): starves the partner wave's loader arithmetic
+#ifndef PP_ABLATE
+#define PP_ABLATE 0
 #endif
 
 constexpr int pp_wait_enc(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }    // s_waitcnt vmcnt(v) only
 
 template <int N> using ic = std::integral_constant<int, N>;
 
-// One LDS-DMA instruction through a buffer descriptor: 16 bytes per lane from (descriptor base + per-lane byte offset)
-// to (wave-uniform LDS address + lane * 16).  An offset past the descriptor's extent writes zeros: the zero padding of
-// the convolution and the rows past the end of the tensor cost no address select and no zero page.
-__device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rs, unsigned off, char *lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, off, 0, 0, 0);
+// One LDS-DMA instruction through a buffer descriptor: 16 bytes per lane from (descriptor base + per-lane byte offset +
+// wave-uniform offset) to (wave-uniform LDS address + lane * 16).  An offset past the descriptor's extent writes zeros:
+// the zero padding of the convolution and the rows past the end of the tensor cost no address select and no zero page.
+__device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rs, unsigned off, char *lds_wave_base, int uniform_off = 0) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, off, uniform_off, 0, 0);
 }
+
+// The workgroup's work list.  Plain: whole tiles blockIdx.x, + gridDim.x, ...  Balanced split (p.sk_slabs != nullptr):
+// the k-step pairs ("units") of an XCD group's tiles are dealt evenly to the group's workgroups, so that no round is
+// partial; a tile cut between two workgroups is summed IN ORDER: the first one runs the head (k-steps 0 .. j - 1, from the
+// bias) as the first thing it does and leaves its fp32 accumulators in its slab, the second one runs the tail as the last
+// thing it does, starting from those accumulators -- the same chain of MFMAs as one workgroup alone: same bits.
+struct PpWork {
+    int nseg, has_head, n_full, first_full, ja, jb, oa2, ob2;     // (oa2 / ob2: k-steps, even)
+    int start, len;                                 // the XCD group's range of logical tiles (balanced split)
+};
+enum { PP_FULL = 0, PP_HEAD = 1, PP_TAIL = 2 };
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_pp_kernel(const ConvArgs p) {
@@ -65,6 +79,56 @@ void conv_pp_kernel(const ConvArgs p) {
     const int nk = p.Kpad >> 6;
     const int total = p.total_tiles;
     const bool reverse = p.flags & Y3_CONV_REVERSE;
+    const bool balanced = p.sk_slabs != nullptr;
+
+    // ---- the work list (wave-uniform scalars) ------------------------------------------------------------------------
+    PpWork wk;
+    if (balanced) {
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3, G = (int)gridDim.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        wk.start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        wk.len = q + (x < r ? 1 : 0);
+        const int npt = nk >> 1;
+        const int U = wk.len * npt;
+        auto cut = [&](int k) {                     // boundary k of the group's G shares, kept 2 units away from tile edges
+            int u = (int)(((long)k * U) / G);
+            const int o = u % npt;
+            if (o < 2) u -= o;
+            else if (o > npt - 2) u += npt - o;
+            return u;
+        };
+        const int u0 = cut(i), u1 = cut(i + 1);
+        wk.ja = u0 / npt;
+        wk.oa2 = 2 * (u0 - wk.ja * npt);
+        wk.jb = u1 > u0 ? (u1 - 1) / npt : wk.ja;
+        wk.ob2 = 2 * (u1 - wk.jb * npt);
+        const int has_tail = wk.oa2 > 0;
+        wk.has_head = u1 > u0 && wk.ob2 < nk;
+        wk.first_full = wk.ja + has_tail;
+        const int last_full = wk.jb - wk.has_head;
+        wk.n_full = u1 > u0 && last_full >= wk.first_full ? last_full - wk.first_full + 1 : 0;
+        wk.nseg = u1 > u0 ? wk.has_head + wk.n_full + has_tail : 0;
+    } else {
+        wk.start = 0; wk.len = total; wk.ja = wk.jb = wk.oa2 = wk.ob2 = wk.has_head = wk.first_full = 0;
+        wk.n_full = (int)blockIdx.x < total ? (total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+        wk.nseg = wk.n_full;
+    }
+    const int tail_seg = balanced && wk.oa2 > 0 ? wk.nseg - 1 : -1;
+    int tail_kt0 = wk.oa2;                          // 0 once the workgroup has decided to recompute the head itself
+    // segment s -> logical tile, first and one-past-last k-step, kind
+    auto segment = [&](int sidx, int &tile, int &kt0, int &kt1, int &kind) {
+        if (!balanced) {
+            tile = xcd_remap((int)blockIdx.x + sidx * (int)gridDim.x, total, reverse);
+            kt0 = 0; kt1 = nk; kind = PP_FULL;
+            return;
+        }
+        int j;
+        const int s2 = sidx - wk.has_head;
+        if (sidx == 0 && wk.has_head) { j = wk.jb; kt0 = 0; kt1 = wk.ob2; kind = PP_HEAD; }
+        else if (s2 < wk.n_full) { j = wk.first_full + s2; kt0 = 0; kt1 = nk; kind = PP_FULL; }
+        else { j = wk.ja; kt0 = tail_kt0; kt1 = nk; kind = PP_TAIL; }
+        tile = wk.start + (reverse ? wk.len - 1 - j : j);
+    };
 
     // the layer's bias: LDS, so that a tile's accumulators start from a ds_read (a global load there would make the
     // compiler drain every LDS-DMA in flight)
@@ -81,14 +145,13 @@ void conv_pp_kernel(const ConvArgs p) {
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, p.w_bytes, 0x00020000);
     const int lrow = tid >> 3;
     const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;       // source chunk (elements) of this LDS slot
-    const int tap0 = kc / p.Cin, cin0 = kc - tap0 * p.Cin;
     int a_base[4];                                  // byte offset of the row's window in the input (< 2 GiB: launcher)
     unsigned a_nmask[4];                            // bit t set = tap t of the row lies OUTSIDE the picture
-    unsigned w_off[4];
+    unsigned w_off = 0;                             // this thread's chunk of its weight row in loader pass 0
     int tap = 0, cin = 0, tapc = 0, toff = 0;
-    int l_tile = blockIdx.x, l_kt = 0, lb = 0, l_m0 = 0;     // wave-uniform: the k-step the loader is on, its LDS buffer
-    bool l_live = l_tile < total;
-#ifdef Y3_EXPERIMENTS                                        // timing experiments of libyolo3hip_exp.so (garbage results)
+    int l_seg = 0, l_kt = 0, l_kt1 = 0, lb = 0, l_m0 = 0;    // wave-uniform: the k-step the loader is on, its LDS buffer
+    bool l_live = wk.nseg > 0, l_newtile = false;
+#if PP_ABLATE          // timing experiments of an A/B build (tools/ab_build.sh abl -DPP_ABLATE=1; garbage results)
     const bool skip_x = p.flags & (1 << 29), skip_w = p.flags & (1 << 28);
 #else
     constexpr bool skip_x = false, skip_w = false;
@@ -106,18 +169,38 @@ void conv_pp_kernel(const ConvArgs p) {
             a_nmask[q] = ~mask;
         }
     };
-    auto l_tile_begin = [&]() {
-        const int bid = xcd_remap(l_tile, total, reverse);
-        const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
-        l_m0 = mt * 256;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {               // LDS row 64 q + lrow = [half][wave column][32 channels]
-            const int idx = lrow + 64 * (q & 1);
-            const int ch = nt * 256 + (idx >> 5) * 64 + (q >> 1) * 32 + (idx & 31);
-            w_off[q] = ((unsigned)ch * (unsigned)p.Kpad + (unsigned)kc) * 2u;
+    // The predecessor's flag, polled by ONE wave, a bounded number of times; the verdict goes to every wave through LDS
+    // (read at least two k-steps = eight barriers later).  Not there in time -> this workgroup computes the head itself.
+    auto decide_tail = [&]() {
+        if (wave == 0) {
+            const unsigned *flag = p.sk_flags + ((int)blockIdx.x - 8);
+            int n = 0;
+            unsigned f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (f == 0u && ++n < PP_SPIN_LIMIT) {
+                __builtin_amdgcn_s_sleep(16);
+                f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#ifdef Y3_EXPERIMENTS
+            if (p.flags & (1 << 30)) f = 0u;        // test hook: always take the recompute path
+#endif
+            *(volatile int *)(smem + PP_DEC) = f != 0u ? 1 : 2;
         }
-        tap = tap0;
-        cin = cin0;
+    };
+    auto l_segment_begin = [&]() {                  // the loader enters segment l_seg
+        int tile, kt0, kind;
+        if (l_seg == tail_seg) tail_kt0 = __builtin_amdgcn_readfirstlane(*(volatile int *)(smem + PP_DEC)) == 1 ? wk.oa2 : 0;
+        segment(l_seg, tile, kt0, l_kt1, kind);
+        l_kt = kt0;
+        const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
+        l_m0 = mt * 256;
+        // LDS row 64 q + lrow of W = [half q >> 1][wave column][32 channels]: channel = (idx >> 5) * 64 + (q >> 1) * 32 +
+        // (idx & 31), idx = lrow + 64 (q & 1) -- pass q is pass 0 moved by 128 (q & 1) + 32 (q >> 1) channels, a uniform offset
+        w_off = ((unsigned)(nt * 256 + (lrow >> 5) * 64 + (lrow & 31)) * (unsigned)p.Kpad + (unsigned)kc) * 2u;
+        const int k = kc + kt0 * 64;                // (kt0 != 0 only for the tail of a cut tile: once per launch)
+        tap = k / p.Cin;
+        cin = k - tap * p.Cin;
+        l_rows(0);                                  // (the rows of X1 are set up a phase later, before their pieces)
+        l_newtile = true;
     };
     auto l_kstep_begin = [&]() {                    // this thread's (tap, channel) of the loader's k-step, then advance
         const int th = p.ks == 3 ? (tap * 11) >> 5 : tap;
@@ -130,17 +213,14 @@ void conv_pp_kernel(const ConvArgs p) {
         cin = wrap ? cin - p.Cin : cin;
         tap = wrap ? tap + 1 : tap;
     };
-    auto l_advance = [&]() {                        // on to the next k-step (of this tile or of the workgroup's next)
+    auto l_advance = [&]() {                        // on to the next k-step (of this segment or of the next)
         ++l_kt;
         lb ^= 1;
-        if (l_kt == nk) {
-            l_kt = 0;
-            l_tile += (int)gridDim.x;
-            l_live = l_tile < total;
-            if (l_live) {
-                l_tile_begin();
-                l_rows(0);                          // (the rows of X1 are set up a phase later, before their pieces)
-            }
+        if (l_seg == tail_seg - 1 && l_kt == l_kt1 - 2) decide_tail();      // (segments are at least four k-steps long)
+        if (l_kt == l_kt1) {
+            ++l_seg;
+            l_live = l_seg < wk.nseg;
+            if (l_live) l_segment_begin();
         }
         if (l_live) l_kstep_begin();
     };
@@ -158,7 +238,8 @@ void conv_pp_kernel(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q = 2 * h + j;
-            bufdma16(rs_w, w_off[q] + (unsigned)(l_kt * 128), smem + PP_W0 + lb * PP_XBUF + q * 8192 + wave * 1024);
+            bufdma16(rs_w, w_off, smem + PP_W0 + lb * PP_XBUF + q * 8192 + wave * 1024,
+                     l_kt * 128 + ((q & 1) * 128 + (q >> 1) * 32) * p.Kpad * 2);
         }
     };
 
@@ -168,14 +249,15 @@ void conv_pp_kernel(const ConvArgs p) {
     const int xb0 = (wm * 128 + frow) * 128 + so0, xb1 = (wm * 128 + frow) * 128 + so1;
     const int wb0 = PP_W0 + (wn * 32 + frow) * 128 + so0, wb1 = PP_W0 + (wn * 32 + frow) * 128 + so1;
 
-    // ---- prologue: k-step 0 complete, k-step 1's X0, W0 and W1 in flight ---------------------------------------------
+    // ---- prologue: the first k-step complete, the second one's X0, W0 and W1 in flight --------------------------------
+    if (tail_seg == 0) decide_tail();               // (a workgroup whose whole share is the tail of one cut tile: rare)
+    __syncthreads();                                // (the bias and the verdict are in LDS; nothing else is outstanding yet)
     if (l_live) {
-        l_tile_begin();
-        l_rows(0);
+        l_segment_begin();
         l_rows(1);
+        l_newtile = false;
         l_kstep_begin();
     }
-    __syncthreads();                                // (the bias is in LDS; nothing else is outstanding yet)
     stage_x(0);
     stage_w(0);
     stage_w(1);
@@ -187,19 +269,32 @@ void conv_pp_kernel(const ConvArgs p) {
     __builtin_amdgcn_s_waitcnt(pp_wait_enc(6));
     __builtin_amdgcn_s_barrier();
 
-    for (int c_tile = blockIdx.x; c_tile < total; c_tile += (int)gridDim.x) {
-    const int bid = xcd_remap(c_tile, total, reverse);
-    const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
+    for (int c_seg = 0; c_seg < wk.nseg; ++c_seg) {
+    int c_tile, c_kt0, c_kt1, c_kind;
+    segment(c_seg, c_tile, c_kt0, c_kt1, c_kind);
+    const int mt = c_tile / p.n_tiles, nt = c_tile - mt * p.n_tiles;
     const int m0 = mt * 256, n0 = nt * 256;
     f32x4 acc[4][8];
+    const int slab_lane = (wave * 64 + lane) * 16;  // slab layout [accumulator 0..31][wave][lane] x 16 bytes
+    if (c_kind == PP_TAIL && c_kt0 != 0) {
+        // the head of this tile was summed by the workgroup before this one (same XCD group): continue from its sums
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const auto rs_prev = __builtin_amdgcn_make_buffer_rsrc((void *)(p.sk_slabs + (long)((int)blockIdx.x - 8) * PP_SLAB), 0, PP_SLAB, 0x00020000);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const f32x4 b0 = *(const f32x4 *)(smem + PP_BIAS + (n0 + wn * 64 + ni * 16 + fq * 4) * 4);
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = b0;
+            for (int mi = 0; mi < 8; ++mi)
+                acc[ni][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_prev, slab_lane, (ni * 8 + mi) * 8192, 16));
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 b0 = *(const f32x4 *)(smem + PP_BIAS + (n0 + wn * 64 + ni * 16 + fq * 4) * 4);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = b0;
+        }
     }
-    // One k-step on LDS buffer CB (compile-time, so that the fragment reads need no address arithmetic; the number of
-    // k-steps is even: y3_conv_pp_ok): two phases of 32 MFMAs.
+    // One k-step on LDS buffer CB (compile-time, so that the fragment reads need no address arithmetic; segments hold an
+    // even number of k-steps): two phases of 32 MFMAs.
     auto kstep = [&](auto CB) {
         constexpr int cb = decltype(CB)::value;
         bf16x8 xf[4][2], wf[4][2];
@@ -242,19 +337,21 @@ void conv_pp_kernel(const ConvArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (PP_PRIO) __builtin_amdgcn_s_setprio(1);
         };
         auto seg_end = [&]() {
-            if (PP_PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (wm == 0) __builtin_amdgcn_s_barrier();
         };
         // phase A: X0 x (W0, W1); requests X1 of the loader's k-step (the next one)
         seg_load();
+        if (l_newtile) {                            // a new tile's X1 rows (its X0 rows were set up at the last phase B);
+            l_rows(1);                              // ahead of the fragment reads, while their 64 registers are free
+            l_newtile = false;
+        }
+        __builtin_amdgcn_sched_barrier(0);
         read_w(ic<0>{});
         read_x(ic<0>{});
         read_w(ic<1>{});
-        if (l_kt == 0 && l_live) l_rows(1);         // a new tile's X1 rows (its X0 rows were set up at the last phase B)
         stage_x(1);
         // X1 of this k-step has landed once only the eight youngest requests remain (the last phase B's six, these two)
         if (l_live) __builtin_amdgcn_s_waitcnt(pp_wait_enc(8));
@@ -265,8 +362,9 @@ void conv_pp_kernel(const ConvArgs p) {
         seg_end();
         // phase B: X1 x (W1, W0); requests X0, W0, W1 of the k-step after the next
         seg_load();
+        l_advance();                                // (ahead of the fragment reads: a new tile's set-up needs registers)
+        __builtin_amdgcn_sched_barrier(0);
         read_x(ic<1>{});
-        l_advance();
         stage_x(0);
         stage_w(0);
         stage_w(1);
@@ -278,11 +376,25 @@ void conv_pp_kernel(const ConvArgs p) {
         mfmas(ic<1>{}, ic<0>{});
         seg_end();
     };
-    for (int kt = 0; kt < nk; kt += 2) {
+    for (int kt = c_kt0; kt < c_kt1; kt += 2) {
         kstep(ic<0>{});
         kstep(ic<1>{});
     }
-#ifdef Y3_EXPERIMENTS
+    if (c_kind == PP_HEAD) {
+        // the head of a cut tile: the fp32 sums go to this workgroup's slab, written through (sc1); every wave drains its
+        // stores, the workgroup meets, ONE lane raises the flag (MI355X hand-off recipe: write-through payload + flag)
+        const auto rs_own = __builtin_amdgcn_make_buffer_rsrc((void *)(p.sk_slabs + (long)blockIdx.x * PP_SLAB), 0, PP_SLAB, 0x00020000);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ni][mi]), rs_own, slab_lane, (ni * 8 + mi) * 8192, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // (one more barrier for every wave: the two groups stay in step)
+        if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+    }
+#if PP_ABLATE
     if (p.flags & (1 << 27)) {                      // timing experiment: no epilogue (one store keeps the accumulators live)
         float sacc = 0.f;
 #pragma unroll
@@ -310,6 +422,19 @@ bool y3_conv_pp_ok(const ConvArgs &a, int n_pad) {
     return true;
 }
 
+// Whether a launch of `nblk` tiles on `grid` persistent workgroups takes the balanced split: an XCD group of grid / 8
+// workgroups shares its tiles' k-step pairs evenly, which needs at least one tile per workgroup (a cut tile then has
+// exactly two owners) and pays only when whole tiles would leave a partial round.
+static bool pp_balanced(long nblk, long grid, long cus) {
+    return grid == cus && cus % 8 == 0 && nblk > grid && nblk % grid != 0 && (nblk >> 3) >= (grid >> 3);
+}
+
+long y3_conv_pp_slab_bytes(const ConvArgs &a, int n_pad, long cus) {
+    const long nblk = (((long)a.M + 255) / 256) * (n_pad / 256);
+    const long grid = nblk <= cus ? nblk : cus;
+    return pp_balanced(nblk, grid, cus) ? grid * (long)PP_SLAB : 0;
+}
+
 int y3_conv_pp_launch(ConvArgs a, int n_pad, long cus, int phase_pct, hipStream_t stream) {
     a.n_tiles = n_pad / 256;
     // extents of the LDS-DMA buffer descriptors: anything past them reads as zero (the loader relies on that)
@@ -330,12 +455,14 @@ int y3_conv_pp_launch(ConvArgs a, int n_pad, long cus, int phase_pct, hipStream_
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv_pp: grid of %ld blocks", nblk); return Y3_E_INVALID; }
     a.total_tiles = (int)nblk;
     const long grid = nblk <= cus ? nblk : cus;          // one workgroup per CU (LDS), persistent over tiles
+    if (!pp_balanced(nblk, grid, cus)) a.sk_slabs = nullptr;      // (a caller's workspace is simply not used)
     // de-phasing as in conv_igemm.hip's launcher: with a spare round, the workgroups that have one tile fewer start
-    // half a tile period late, so that their epilogues fall into the others' main loops
+    // half a tile period late, so that their epilogues fall into the others' main loops (the balanced split has no
+    // spare round and de-phases the workgroups by itself: every one starts with a different share of a cut tile)
     a.delay_ticks = 0;
     a.delay_from = 0;
     const long rem = nblk % grid;
-    if (grid == cus && nblk >= 4 * cus && rem != 0 && phase_pct > 0) {
+    if (a.sk_slabs == nullptr && grid == cus && nblk >= 4 * cus && rem != 0 && phase_pct > 0) {
         const double tile_us = 2.0 * 256 * 256 * (double)a.Kpad / 5.4e6;          // at ~5.4 TFLOP/s per CU
         a.delay_ticks = (unsigned)(tile_us * phase_pct);                          // 100 ticks per us, percent
         a.delay_from = (int)rem;
