@@ -358,6 +358,52 @@ def test_conv_pingpong_kernel_equals_the_implicit_gemm(case):
         np.testing.assert_array_equal(outs[512], outs[key], err_msg=str(key))
 
 
+@pytest.mark.parametrize("B,H,C,O,stride,res,split", [(64, 19, 512, 1024, 1, True, False), (64, 38, 256, 512, 1, True, True)])
+def test_conv_workspace_with_the_library_own_tile_choice(B, H, C, O, stride, res, split):
+    """The product library's own choice (no tile forced): y3_conv2d_fused_ws deals the k-steps evenly on the launches that
+    run on the 256 x 256 tile anyway (38 x 38: 2.8 rounds) and ignores the workspace on the others (19 x 19 at batch 64
+    keeps its 192-pixel tiles: y3_conv_workspace_bytes says 0) -- the same bits either way."""
+    rng = np.random.default_rng(B + H + C)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, H, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((3, 3, C, O)) * np.sqrt(2.0 / (9 * C))).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    Ho = H // stride
+    r = gpu_util.bf16_round(rng.standard_normal((B, Ho, Ho, O)).astype(np.float32)) if res else None
+    plain = gpu_util.run_conv(x, k, b, stride, "bf16", leaky=True, residual=r)
+    info = {}
+    with_ws = gpu_util.run_conv(x, k, b, stride, "bf16", leaky=True, residual=r, ws=True, info=info)
+    assert (info["slab_bytes"] > 0) == split and (info["flags_raised"] > 100) == split, info
+    np.testing.assert_array_equal(plain, with_ws)
+
+
+@pytest.mark.parametrize("B,H,C,O", [(64, 76, 128, 256), (40, 76, 128, 256), (29, 76, 128, 256), (64, 38, 256, 512), (37, 38, 256, 512)])
+def test_conv_balanced_split_after_whole_rounds(B, H, C, O):
+    """Launches of several rounds: whole rounds first, then the remaining tiles' k-steps dealt evenly -- half a tile to a
+    tile per workgroup, so tiles are cut into up to three pieces (first k-steps, middle, last k-steps; tests/
+    test_pp_partition.py restates the work list).  Bit for bit the unsplit kernel's output, both tile orders and with
+    every piece that could continue a predecessor's sums recomputing them instead; sanity against torch's fp32 conv."""
+    import torch
+    from yolo_amd import _lib
+    rng = np.random.default_rng(B + H)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, H, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((3, 3, C, O)) * np.sqrt(2.0 / (9 * C))).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    r = gpu_util.bf16_round(rng.standard_normal((B, H, H, O)).astype(np.float32))
+    outs, info = {}, {}
+    with _lib.experimental() as exp:
+        _lib.check(exp.y3_set_conv_tile(512))
+        outs["plain"] = gpu_util.run_conv(x, k, b, 1, "bf16", residual=r)
+        outs["ws"] = gpu_util.run_conv(x, k, b, 1, "bf16", residual=r, ws=True, info=info)
+        outs["ws_rev"] = gpu_util.run_conv(x, k, b, 1, "bf16", residual=r, ws=True, reverse=True)
+        outs["ws_recompute"] = gpu_util.run_conv(x, k, b, 1, "bf16", residual=r, ws=True, extra_flags=1 << 30)
+    assert info["slab_bytes"] > 0 and info["flags_raised"] > 100, info
+    for key in ("ws", "ws_rev", "ws_recompute"):
+        np.testing.assert_array_equal(outs["plain"], outs[key], err_msg=key)
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).cuda().permute(0, 3, 1, 2), torch.from_numpy(k).cuda().permute(3, 2, 0, 1), torch.from_numpy(b).cuda(), padding=1)
+    want = (torch.nn.functional.leaky_relu(y, 0.1).permute(0, 2, 3, 1) + torch.from_numpy(r).cuda()).cpu().numpy()
+    assert np.all(np.abs(outs["plain"] - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
+
+
 def test_conv_pingpong_is_what_the_big_layers_run_on():
     """y3_conv_kernel_name: the product library sends the 256 x 256-tile launches with a bf16 output to conv_pp_kernel
     (the fp32 heads keep conv_igemm_kernel's LDS epilogue with the fused decode)."""

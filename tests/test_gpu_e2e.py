@@ -529,6 +529,26 @@ def test_snake_tile_order_is_only_a_schedule():
         np.testing.assert_array_equal(a, b)
 
 
+def test_balanced_split_in_the_plan_is_only_a_schedule():
+    """Network(balanced=True): the launches that leave a partial round of 256 x 256 tiles go through y3_conv2d_fused_ws
+    (one slab buffer for the plan, one block of flags per launch, zeroed once per pass) -- heads bit-identical to the
+    default plan's, on two passes in a row (the flags of the first must not leak into the second)."""
+    layers, oi = od.parse_layers(config.yolov3_cfg_path, 80)
+    params = dw.random_params(layers, seed=8)
+    x = torch.from_numpy(np.random.default_rng(8).random((16, 608, 608, 3), dtype=np.float32))
+    outs = []
+    for balanced in (False, True, True):
+        if len(outs) < 2:
+            net = build_model.Network(config.yolov3_cfg_path, 80, dtype="bf16", balanced=balanced)
+            net.set_params(params)
+        plan = net.plan_for(16, 608, 608).plan
+        assert any(op.get("balanced") for op in plan.ops) == balanced
+        outs.append([h.cpu().numpy() for h in net(x)])
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_graphed_detector_equals_eager_path():
     """graph.GraphedDetector: one HIP graph per step (backbone + decode + NMS + pack), replayed on a static input
     buffer.  Same kernels as the eager path -> identical detections, also after the input and the source image

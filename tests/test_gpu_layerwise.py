@@ -49,6 +49,7 @@ def test_every_launch_against_bf16_model_teacher_forced(cfg_name, size, batch, r
     from yolo_amd import _lib
     checked = flipped = total = 0
     worst = 0.0
+    cp.begin_pass()
     for op, launch in zip(cp.plan.ops, cp.launchers):
         _lib.check(launch(env))
         torch.cuda.synchronize()

@@ -77,9 +77,22 @@ class _CompiledPlan(object):
                     need = max(need, self._splitk_bytes(net, op))
         if need:
             self._splitk_ws = torch.empty(need, dtype=torch.uint8, device=net.device)
+        # y3_conv2d_fused_ws (the 256 x 256-tile kernel's balanced split): fp32 slabs shared by the plan's launches (they
+        # run in order on one stream) and one block of flags per launch, all zeroed by ONE memset at the start of a pass
+        self._ws_slab_bytes, self._ws_ops, self._ws_slabs, self._ws_flags = 0, 0, None, None
+        self._ws_ptrs = [0, 0]          # slabs, flags (read by the launch closures at launch time)
         self.head_ops = {}              # head index -> what a fused head-decode launch of that op needs (_prepare)
         self._decode = {}               # PostProcessor id -> (DecodeDesc for this plan's batch, fused launchers or None)
         self.launchers = [self._prepare(net, op) for op in plan.ops]
+        if self._ws_ops:
+            self._ws_slabs = torch.empty(self._ws_slab_bytes, dtype=torch.uint8, device=net.device)
+            self._ws_flags = torch.zeros(self._ws_ops * 256, dtype=torch.int32, device=net.device)
+            self._ws_ptrs[0], self._ws_ptrs[1] = self._ws_slabs.data_ptr(), self._ws_flags.data_ptr()
+
+    def begin_pass(self):
+        """Before the launches of one pass through the plan: the hand-off flags of y3_conv2d_fused_ws start at zero."""
+        if self._ws_flags is not None:
+            self._ws_flags.zero_()
 
     def decode_launchers(self, pp):
         """Launch list of this plan with the YOLO decode fused into the head convolutions (y3_conv2d_head_decode), for
@@ -198,6 +211,20 @@ class _CompiledPlan(object):
             if op["out_f32"] and op["y"]["buf"][0] == "head" and not net.splitk:
                 self.head_ops[op["y"]["buf"][1]] = dict(dref=dref, x=x, y=y, w=wp, b=bp, z=zp, index=plan.ops.index(op), keep=(d, w, bias))
 
+            if net.balanced and not net.splitk:
+                nbytes = ctypes.c_int64(0)
+                _lib.check(lib.y3_conv_workspace_bytes(dref, ctypes.byref(nbytes)))
+                if nbytes.value > 0:        # several rounds of 256 x 256 tiles with a partial last one: deal the k-steps evenly
+                    k_ws, ptrs, nb_ws, fws = self._ws_ops, self._ws_ptrs, int(nbytes.value), lib.y3_conv2d_fused_ws
+                    self._ws_ops += 1
+                    self._ws_slab_bytes = max(self._ws_slab_bytes, nb_ws)
+                    op["balanced"] = True
+                    op["kernel"] = "conv_pp_kernel"     # (with the workspace the tile choice can differ from y3_conv_kernel_name's)
+
+                    def launch_ws(env, _keep=(d, w, bias)):
+                        return fws(dref, x(env), wp, bp, r(env), y(env), zp, ptrs[0], nb_ws, ptrs[1] + k_ws * 1024, env["stream"])
+                    return launch_ws
+
             def launch(env, _keep=(d, w, bias)):
                 return fn(dref, x(env), wp, bp, r(env), y(env), zp, env["stream"])
             return launch
@@ -281,7 +308,7 @@ class Network(object):
     """The compiled detector: cfg layers + packed device weights + cached launch plans."""
 
     def __init__(self, config_path, num_classes, dtype=None, device=None, fuse=True, pad_input=False, stem=True,
-                 snake=None, splitk=False, resblock=None):
+                 snake=None, splitk=False, resblock=None, balanced=None):
         self.config_path = config_path
         self.num_classes = num_classes
         self.dtype = dtype or config.compute_dtype
@@ -297,6 +324,9 @@ class Network(object):
         # split-K for launches with few output tiles (small batches: latency mode).  Off by default: split sums are
         # added in another order, so results are no longer bit-identical across batch sizes / chunking.
         self.splitk = bool(splitk)
+        # y3_conv2d_fused_ws for the launches that leave a partial round of 256 x 256 tiles: same bits, but measured 4 - 8 %
+        # SLOWER per layer inside the network (profiles/r03e), so off unless asked for (YOLO_AMD_BALANCED=1: A/B)
+        self.balanced = (os.environ.get("YOLO_AMD_BALANCED", "0") == "1") if balanced is None else bool(balanced)
         # residual blocks (1x1 -> 3x3 -> shortcut) as one launch: None = where the planner finds it pays (bf16, large
         # launches), False = never; YOLO_AMD_RESBLOCK=0 for A/B runs.  Same bits either way.
         if resblock is None and os.environ.get("YOLO_AMD_RESBLOCK") == "0":
@@ -386,6 +416,7 @@ class Network(object):
             env = {"in": in_base + b0 * H * W * 3 * 4, "stream": stream,
                    "heads": [h.data_ptr() + b0 * h.stride(0) * 4 for h in heads] if want_heads else [0] * len(first.plan.heads)}
             launchers = cp.launchers
+            cp.begin_pass()
             if fused is not None:
                 ws, N, C = decode["ws"], fused[nb][0].boxes_per_image, fused[nb][0].num_classes
                 env["decode"] = dict(store_heads=bool(decode["store_heads"]),

@@ -18,6 +18,7 @@ struct ConvArgs {
     int total_tiles;
     int delay_from;                    // persistent workgroups with blockIdx.x >= delay_from start delay_ticks late
     unsigned delay_ticks;              // in s_memrealtime ticks (100 MHz)
+    int lock_rounds;                   // conv_pp_kernel's balanced split: whole rounds of tiles before the dealt remainder
     int splits, nk_split;              // split-K: a tile's k-steps are dealt to `splits` workgroups, nk_split each
     long slice_elems;                  // ... which write fp32 partial sums to out + split * slice_elems
 };

@@ -59,15 +59,20 @@ __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rs, unsigned off
 }
 
 // The workgroup's work list.  Plain: whole tiles blockIdx.x, + gridDim.x, ...  Balanced split (p.sk_slabs != nullptr):
-// the k-step pairs ("units") of an XCD group's tiles are dealt evenly to the group's workgroups, so that no round is
-// partial; a tile cut between two workgroups is summed IN ORDER: the first one runs the head (k-steps 0 .. j - 1, from the
-// bias) as the first thing it does and leaves its fp32 accumulators in its slab, the second one runs the tail as the last
-// thing it does, starting from those accumulators -- the same chain of MFMAs as one workgroup alone: same bits.
+// an XCD group of G workgroups first shares p.lock_rounds whole rounds of its tiles as before (workgroup i: tiles i, i + G,
+// ...: neighbouring tiles run at the same time on one L2, and the walk through the tensor stays the one the layers before
+// and after expect), and the k-step pairs ("units") of the REMAINING tiles -- between half a tile and a tile and a half per
+// workgroup -- are dealt evenly, each workgroup a contiguous range of them.  A tile cut between workgroups is summed IN
+// ORDER: whoever has its first k-steps (PP_HEAD, from the bias) runs them as the first thing it does and leaves the fp32
+// accumulators in its slab; a piece from the middle of a tile (PP_MID: slab in, slab out) runs after the workgroup's first
+// whole tile, by when the head is long done; the last k-steps (PP_TAIL) are the last thing a workgroup does, starting from
+// the predecessor's accumulators -- the same chain of MFMAs as one workgroup alone: same bits.  A range lies within two
+// neighbouring tiles, so a workgroup leaves at most one slab and takes at most one, always its predecessor's.
 struct PpWork {
-    int nseg, has_head, n_full, first_full, ja, jb, oa2, ob2;     // (oa2 / ob2: k-steps, even)
-    int start, len;                                 // the XCD group's range of logical tiles (balanced split)
+    int nseg, has_head, has_mid, mid_at, rl, n_full, first_full, ja, jb, oa2, ob2;     // (oa2 / ob2: k-steps, even)
+    int start, len, i, G;                           // the XCD group's range of logical tiles, this workgroup's place in it
 };
-enum { PP_FULL = 0, PP_HEAD = 1, PP_TAIL = 2 };
+enum { PP_FULL = 0, PP_HEAD = 1, PP_TAIL = 2, PP_MID = 3 };
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_pp_kernel(const ConvArgs p) {
@@ -83,38 +88,46 @@ void conv_pp_kernel(const ConvArgs p) {
 
     // ---- the work list (wave-uniform scalars) ------------------------------------------------------------------------
     PpWork wk;
+    int cons_seg = -1;                              // the segment that starts from the predecessor's slab (PP_TAIL / PP_MID)
     if (balanced) {
-        const int x = blockIdx.x & 7, i = blockIdx.x >> 3, G = (int)gridDim.x >> 3;
-        const int q = total >> 3, r = total & 7;
+        const int x = blockIdx.x & 7, q = total >> 3, r = total & 7;
+        wk.i = blockIdx.x >> 3;
+        wk.G = (int)gridDim.x >> 3;
         wk.start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
         wk.len = q + (x < r ? 1 : 0);
+        wk.rl = p.lock_rounds;
         const int npt = nk >> 1;
-        const int U = wk.len * npt;
+        const int U = (wk.len - wk.rl * wk.G) * npt;        // units of the tiles behind the whole rounds
         auto cut = [&](int k) {                     // boundary k of the group's G shares, kept 2 units away from tile edges
-            int u = (int)(((long)k * U) / G);
+            int u = (int)(((long)k * U) / wk.G);
             const int o = u % npt;
             if (o < 2) u -= o;
             else if (o > npt - 2) u += npt - o;
             return u;
         };
-        const int u0 = cut(i), u1 = cut(i + 1);
+        const int u0 = cut(wk.i), u1 = cut(wk.i + 1);
+        const bool any = u1 > u0;
         wk.ja = u0 / npt;
-        wk.oa2 = 2 * (u0 - wk.ja * npt);
-        wk.jb = u1 > u0 ? (u1 - 1) / npt : wk.ja;
-        wk.ob2 = 2 * (u1 - wk.jb * npt);
-        const int has_tail = wk.oa2 > 0;
-        wk.has_head = u1 > u0 && wk.ob2 < nk;
+        wk.oa2 = any ? 2 * (u0 - wk.ja * npt) : 0;
+        wk.jb = any ? (u1 - 1) / npt : wk.ja;
+        wk.ob2 = any ? 2 * (u1 - wk.jb * npt) : nk;
+        wk.has_mid = any && wk.ja == wk.jb && wk.oa2 > 0 && wk.ob2 < nk;
+        const int has_tail = wk.oa2 > 0 && !wk.has_mid;
+        wk.has_head = any && wk.ob2 < nk && !wk.has_mid;
+        wk.mid_at = wk.rl > 0 ? 1 : 0;
         wk.first_full = wk.ja + has_tail;
         const int last_full = wk.jb - wk.has_head;
-        wk.n_full = u1 > u0 && last_full >= wk.first_full ? last_full - wk.first_full + 1 : 0;
-        wk.nseg = u1 > u0 ? wk.has_head + wk.n_full + has_tail : 0;
+        wk.n_full = any && !wk.has_mid && last_full >= wk.first_full ? last_full - wk.first_full + 1 : 0;
+        wk.nseg = wk.rl + wk.has_head + wk.has_mid + wk.n_full + has_tail;
+        cons_seg = has_tail ? wk.nseg - 1 : (wk.has_mid ? wk.mid_at : -1);
     } else {
-        wk.start = 0; wk.len = total; wk.ja = wk.jb = wk.oa2 = wk.ob2 = wk.has_head = wk.first_full = 0;
-        wk.n_full = (int)blockIdx.x < total ? (total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-        wk.nseg = wk.n_full;
+        wk.start = 0; wk.len = total; wk.ja = wk.jb = wk.oa2 = wk.ob2 = wk.has_head = wk.has_mid = wk.mid_at = wk.first_full = 0;
+        wk.i = (int)blockIdx.x; wk.G = (int)gridDim.x;
+        wk.rl = (int)blockIdx.x < total ? (total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+        wk.n_full = 0;
+        wk.nseg = wk.rl;
     }
-    const int tail_seg = balanced && wk.oa2 > 0 ? wk.nseg - 1 : -1;
-    int tail_kt0 = wk.oa2;                          // 0 once the workgroup has decided to recompute the head itself
+    int cons_kt0 = wk.oa2;                          // 0 once the workgroup has decided to recompute the tile's first k-steps itself
     // segment s -> logical tile, first and one-past-last k-step, kind
     auto segment = [&](int sidx, int &tile, int &kt0, int &kt1, int &kind) {
         if (!balanced) {
@@ -122,11 +135,22 @@ void conv_pp_kernel(const ConvArgs p) {
             kt0 = 0; kt1 = nk; kind = PP_FULL;
             return;
         }
-        int j;
-        const int s2 = sidx - wk.has_head;
-        if (sidx == 0 && wk.has_head) { j = wk.jb; kt0 = 0; kt1 = wk.ob2; kind = PP_HEAD; }
-        else if (s2 < wk.n_full) { j = wk.first_full + s2; kt0 = 0; kt1 = nk; kind = PP_FULL; }
-        else { j = wk.ja; kt0 = tail_kt0; kt1 = nk; kind = PP_TAIL; }
+        int j, s = sidx;
+        kt0 = 0; kt1 = nk; kind = PP_FULL;
+        bool done = false;
+        if (wk.has_head) {
+            if (s == 0) { j = wk.rl * wk.G + wk.jb; kt1 = wk.ob2; kind = PP_HEAD; done = true; }
+            --s;
+        }
+        if (!done && wk.has_mid) {
+            if (s == wk.mid_at) { j = wk.rl * wk.G + wk.ja; kt0 = cons_kt0; kt1 = wk.ob2; kind = PP_MID; done = true; }
+            else if (s > wk.mid_at) --s;
+        }
+        if (!done) {
+            if (s < wk.rl) j = wk.i + s * wk.G;                                  // a whole round's tile
+            else if (s - wk.rl < wk.n_full) j = wk.rl * wk.G + wk.first_full + (s - wk.rl);
+            else { j = wk.rl * wk.G + wk.ja; kt0 = cons_kt0; kind = PP_TAIL; }
+        }
         tile = wk.start + (reverse ? wk.len - 1 - j : j);
     };
 
@@ -182,13 +206,15 @@ void conv_pp_kernel(const ConvArgs p) {
             }
 #ifdef Y3_EXPERIMENTS
             if (p.flags & (1 << 30)) f = 0u;        // test hook: always take the recompute path
+            // what the poll saw, for tools/pp_split_probe.py: polls << 8 | 3 (partial sums taken) or 5 (recomputed)
+            if (lane == 0) __hip_atomic_store(p.sk_flags + ((int)blockIdx.x - 8), ((unsigned)n << 8) | (f != 0u ? 3u : 5u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
             *(volatile int *)(smem + PP_DEC) = f != 0u ? 1 : 2;
         }
     };
     auto l_segment_begin = [&]() {                  // the loader enters segment l_seg
         int tile, kt0, kind;
-        if (l_seg == tail_seg) tail_kt0 = __builtin_amdgcn_readfirstlane(*(volatile int *)(smem + PP_DEC)) == 1 ? wk.oa2 : 0;
+        if (l_seg == cons_seg) cons_kt0 = __builtin_amdgcn_readfirstlane(*(volatile int *)(smem + PP_DEC)) == 1 ? wk.oa2 : 0;
         segment(l_seg, tile, kt0, l_kt1, kind);
         l_kt = kt0;
         const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
@@ -216,7 +242,7 @@ void conv_pp_kernel(const ConvArgs p) {
     auto l_advance = [&]() {                        // on to the next k-step (of this segment or of the next)
         ++l_kt;
         lb ^= 1;
-        if (l_seg == tail_seg - 1 && l_kt == l_kt1 - 2) decide_tail();      // (segments are at least four k-steps long)
+        if (l_seg == cons_seg - 1 && l_kt == l_kt1 - 2) decide_tail();      // (segments are at least four k-steps long)
         if (l_kt == l_kt1) {
             ++l_seg;
             l_live = l_seg < wk.nseg;
@@ -250,7 +276,7 @@ void conv_pp_kernel(const ConvArgs p) {
     const int wb0 = PP_W0 + (wn * 32 + frow) * 128 + so0, wb1 = PP_W0 + (wn * 32 + frow) * 128 + so1;
 
     // ---- prologue: the first k-step complete, the second one's X0, W0 and W1 in flight --------------------------------
-    if (tail_seg == 0) decide_tail();               // (a workgroup whose whole share is the tail of one cut tile: rare)
+    if (cons_seg == 0) decide_tail();               // (a workgroup that starts with the tail of a cut tile: no whole rounds)
     __syncthreads();                                // (the bias and the verdict are in LDS; nothing else is outstanding yet)
     if (l_live) {
         l_segment_begin();
@@ -276,8 +302,8 @@ void conv_pp_kernel(const ConvArgs p) {
     const int m0 = mt * 256, n0 = nt * 256;
     f32x4 acc[4][8];
     const int slab_lane = (wave * 64 + lane) * 16;  // slab layout [accumulator 0..31][wave][lane] x 16 bytes
-    if (c_kind == PP_TAIL && c_kt0 != 0) {
-        // the head of this tile was summed by the workgroup before this one (same XCD group): continue from its sums
+    if ((c_kind == PP_TAIL || c_kind == PP_MID) && c_kt0 != 0) {
+        // the k-steps before these were summed by the workgroup before this one (same XCD group): continue from its sums
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const auto rs_prev = __builtin_amdgcn_make_buffer_rsrc((void *)(p.sk_slabs + (long)((int)blockIdx.x - 8) * PP_SLAB), 0, PP_SLAB, 0x00020000);
 #pragma unroll
@@ -380,8 +406,8 @@ void conv_pp_kernel(const ConvArgs p) {
         kstep(ic<0>{});
         kstep(ic<1>{});
     }
-    if (c_kind == PP_HEAD) {
-        // the head of a cut tile: the fp32 sums go to this workgroup's slab, written through (sc1); every wave drains its
+    if (c_kind == PP_HEAD || c_kind == PP_MID) {
+        // a cut tile with k-steps still to come: the fp32 sums go to this workgroup's slab, written through (sc1); every wave drains its
         // stores, the workgroup meets, ONE lane raises the flag (MI355X hand-off recipe: write-through payload + flag)
         const auto rs_own = __builtin_amdgcn_make_buffer_rsrc((void *)(p.sk_slabs + (long)blockIdx.x * PP_SLAB), 0, PP_SLAB, 0x00020000);
 #pragma unroll
@@ -456,6 +482,16 @@ int y3_conv_pp_launch(ConvArgs a, int n_pad, long cus, int phase_pct, hipStream_
     a.total_tiles = (int)nblk;
     const long grid = nblk <= cus ? nblk : cus;          // one workgroup per CU (LDS), persistent over tiles
     if (!pp_balanced(nblk, grid, cus)) a.sk_slabs = nullptr;      // (a caller's workspace is simply not used)
+    // whole rounds first, as many as leave at least half a tile per workgroup to deal out: cut tiles then have at most
+    // three owners, and a piece from the middle of a tile never has to wait for another one
+    a.lock_rounds = 0;
+    if (a.sk_slabs != nullptr) {
+        const long q = nblk >> 3, G = grid >> 3;
+        a.lock_rounds = (int)((2 * q - G) / (2 * G));
+#ifdef PP_NO_LOCK_ROUNDS
+        a.lock_rounds = 0;                          // A/B build: everything dealt as one contiguous range per workgroup
+#endif
+    }
     // de-phasing as in conv_igemm.hip's launcher: with a spare round, the workgroups that have one tile fewer start
     // half a tile period late, so that their epilogues fall into the others' main loops (the balanced split has no
     // spare round and de-phases the workgroups by itself: every one starts with a different share of a cut tile)
