@@ -272,7 +272,7 @@ def main():
             achieved = dom_flops / (dom_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": None,
-                               "kernel": dom + ">", "launches_per_step": dom_n // len(traces),
+                               "kernel": dom + (">" if "<" in dom else ""), "launches_per_step": dom_n // len(traces),
                                "avg_launch_ms": round(dom_ms / dom_n, 4),
                                "avg_gflop_per_launch": round(dom_flops / dom_n / 1e9, 3),
                                "share_of_step": round(dom_ms / len(traces) / (1e3 * elapsed / args.steps), 3),
@@ -299,7 +299,7 @@ def main():
                 if op["kind"] in ("conv", "stem", "resblock"):
                     v = wk.setdefault(op["kernel"], [0.0, 0.0, 0])
                     v[0] += e0.elapsed_time(e1); v[1] += conv_flops(op, nb); v[2] += 1
-            out["kernels"] = {k + ">": {"ms_per_step": round(v[0], 3), "launches_per_step": v[2],
+            out["kernels"] = {k + (">" if "<" in k else ""): {"ms_per_step": round(v[0], 3), "launches_per_step": v[2],
                                         "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in wk.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, S, args.cpu_images, args.score_threshold)

@@ -535,13 +535,14 @@ def test_balanced_split_in_the_plan_is_only_a_schedule():
     default plan's, on two passes in a row (the flags of the first must not leak into the second)."""
     layers, oi = od.parse_layers(config.yolov3_cfg_path, 80)
     params = dw.random_params(layers, seed=8)
-    x = torch.from_numpy(np.random.default_rng(8).random((16, 608, 608, 3), dtype=np.float32))
+    B = 22          # 497 tiles of 256 x 256 at 76 x 76: 1.94 rounds on 256 workgroups, the library's choice there
+    x = torch.from_numpy(np.random.default_rng(8).random((B, 608, 608, 3), dtype=np.float32))
     outs = []
     for balanced in (False, True, True):
         if len(outs) < 2:
             net = build_model.Network(config.yolov3_cfg_path, 80, dtype="bf16", balanced=balanced)
             net.set_params(params)
-        plan = net.plan_for(16, 608, 608).plan
+        plan = net.plan_for(B, 608, 608).plan
         assert any(op.get("balanced") for op in plan.ops) == balanced
         outs.append([h.cpu().numpy() for h in net(x)])
     for other in outs[1:]:
