@@ -89,6 +89,11 @@ def cpu_baseline(model_cfg, size, n_images, score_threshold):
                       % (n_images, size, size)}
 
 
+def _closed(name):
+    """A kernel name as the plan carries it (template arguments cut short) with its bracket closed."""
+    return name + ">" * max(0, name.count("<") - name.count(">"))
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` started without a launcher: start N fresh child ranks under torch.distributed.run
     (one process per GPU, RCCL), relay rank 0's JSON line and exit with the launcher's code.  This process never
@@ -272,7 +277,7 @@ def main():
             achieved = dom_flops / (dom_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": None,
-                               "kernel": dom + (">" if "<" in dom else ""), "launches_per_step": dom_n // len(traces),
+                               "kernel": _closed(dom), "launches_per_step": dom_n // len(traces),
                                "avg_launch_ms": round(dom_ms / dom_n, 4),
                                "avg_gflop_per_launch": round(dom_flops / dom_n / 1e9, 3),
                                "share_of_step": round(dom_ms / len(traces) / (1e3 * elapsed / args.steps), 3),
@@ -299,7 +304,7 @@ def main():
                 if op["kind"] in ("conv", "stem", "resblock"):
                     v = wk.setdefault(op["kernel"], [0.0, 0.0, 0])
                     v[0] += e0.elapsed_time(e1); v[1] += conv_flops(op, nb); v[2] += 1
-            out["kernels"] = {k + (">" if "<" in k else ""): {"ms_per_step": round(v[0], 3), "launches_per_step": v[2],
+            out["kernels"] = {_closed(k): {"ms_per_step": round(v[0], 3), "launches_per_step": v[2],
                                         "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in wk.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, S, args.cpu_images, args.score_threshold)
