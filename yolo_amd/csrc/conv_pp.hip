@@ -41,6 +41,9 @@ constexpr int PP_MAX_COUT = 2048;
 constexpr int PP_DEC = PP_BIAS + PP_MAX_COUT * 4;   // balanced split: 1 = the predecessor's partial sums are there, 2 = recompute
 constexpr int PP_LDS = PP_DEC + 16;
 constexpr int PP_SLAB = 256 * 256 * 4;              // bytes of one workgroup's fp32 partial sums (balanced split)
+#ifndef PP_SLAB_AUX
+#define PP_SLAB_AUX 16                              // cache policy of the slab accesses: sc1 (agent scope, written through)
+#endif
 constexpr int PP_SPIN_LIMIT = 1 << 17;              // polls of the predecessor's flag before giving up and recomputing
 
 #ifndef PP_ABLATE
@@ -310,7 +313,7 @@ void conv_pp_kernel(const ConvArgs p) {
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
-                acc[ni][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_prev, slab_lane, (ni * 8 + mi) * 8192, 16));
+                acc[ni][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_prev, slab_lane, (ni * 8 + mi) * 8192, PP_SLAB_AUX));
     } else {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -414,7 +417,7 @@ void conv_pp_kernel(const ConvArgs p) {
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ni][mi]), rs_own, slab_lane, (ni * 8 + mi) * 8192, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ni][mi]), rs_own, slab_lane, (ni * 8 + mi) * 8192, PP_SLAB_AUX);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // (one more barrier for every wave: the two groups stay in step)
         if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
