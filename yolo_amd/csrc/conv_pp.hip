@@ -1,5 +1,5 @@
 // Implicit-GEMM convolution, 256 pixels x 256 channels per workgroup, bf16, register epilogue -- the "ping-pong"
-// (8-phase) main loop for gfx950.  Same GEMM view, same packed weights, same LDS image (128-byte rows, 16-byte chunks
+// main loop for gfx950.  Same GEMM view, same packed weights, same LDS image (128-byte rows, 16-byte chunks
 // XOR-swizzled by (row >> 1) & 7 on the source address and on the fragment read) and the same per-accumulator sum order
 // (bias first, 32-deep k blocks ascending) as conv_igemm_kernel<true, 256, 256, 2, 4>, hence the same bits
 // (tests/test_gpu_conv.py); conv_igemm.hip's launcher dispatches the layers that tile would run to this kernel.
@@ -7,25 +7,36 @@
 //
 // Why another main loop.  conv_igemm_kernel has one barrier per 64-deep k-step: all eight waves read their twelve
 // fragments at once, wait for all of them, and issue 64 MFMAs each; the two waves of a SIMD run in lockstep, so the
-// matrix pipe idles through every LDS read burst and every LDS-DMA issue (an LDS-DMA instruction holds its wave for
-// 60-180 cycles).  Measured with the loads and the epilogue removed (profiles/r03a): 1 380-1 510 TFLOP/s, i.e. the
-// loop's own structure costs a third of the pipe.  Here a k-step is cut into FOUR phases of 16 MFMAs (one quadrant of
-// the wave's 128 x 64 tile, both 32-deep halves), and the two wave groups (waves 0-3 / 4-7 = the two waves of every
-// SIMD) run half a phase apart: while one group issues its 16 MFMAs the other reads the next quadrant's fragments and
-// issues its two LDS-DMA pieces, then they swap.  Two s_barriers per phase keep the alternation exact.
+// matrix pipe idles through every LDS read burst and every LDS-DMA issue.  Measured with the loads and the epilogue
+// removed (profiles/r03a): 1 380-1 510 TFLOP/s, i.e. the loop's own structure costs a third of the pipe.  Here a k-step
+// is cut into TWO phases of 32 MFMAs (half of the wave's 128 x 64 tile, both 32-deep halves), and the two wave groups
+// (waves 0-3 / 4-7 = the two waves of every SIMD) run half a phase apart: while one group issues its 32 MFMAs the other
+// reads the next half's fragments and issues its LDS-DMA pieces, then they swap.  Two s_barriers per phase keep the
+// alternation exact (the group that runs behind meets its barrier first, the one ahead last).
 //
-//   group 0:  L1 | M1 | L2 | M2 | L3 | M3 | L4 | M4 | L1' ...          L = fragment reads + 2 LDS-DMA pieces (+ waits)
-//   group 1:     | L1 | M1 | L2 | M2 | L3 | M3 | L4 | M4 ...           M = 16 MFMAs         | = s_barrier
+//   group 0:  LA | MA | LB | MB | LA' ...          L = fragment reads + LDS-DMA pieces + counted wait     M = 32 MFMAs
+//   group 1:     | LA | MA | LB | MB ...           | = s_barrier
 //
 // A k-step's operands are four half-tiles of 16 KB: X0 / X1 = the pixel rows of the waves' first / second 64 pixels,
 // W0 / W1 = the channel rows of their first / second 32 channels (W rows are stored [half][wave column][32]).
-// Phases:   1: read W0 X0, MFMA (X0, W0)    2: read W1, MFMA (X0, W1)    3: read X1, MFMA (X1, W1)    4: read W0 again,
-// MFMA (X1, W0) -- 28 fragment reads per k-step for 48 fragment registers.  The loader runs ahead of the MFMAs across
-// k-steps AND tiles: k-step u's half-tiles are requested in the order X0, W1 (phases 3, 4 of k-step u - 2), X1, W0
-// (phases 1, 2 of k-step u - 1), each at least two phases after the last read of the bytes it overwrites, and retired
-// by ONE counted wait per k-step: phase 4 waits until only its four youngest requests are outstanding (k-step u + 2's
-// X0, W1), which leaves k-step u + 1 complete; the barrier after it publishes that to the other waves, whose first read
-// of it is a phase later.  The next tile's first k-steps are therefore in LDS before this tile's epilogue starts.
+// Phase A reads W0, X0, W1 (16 ds_read_b128) and multiplies X0 by both; phase B reads X1 (8) and multiplies it by W1 and
+// W0, which are still in registers: 24 fragment reads per k-step.  What was tried on the way (profiles/r03d): four
+// phases of 16 MFMAs were 12-19 % SLOWER than conv_igemm_kernel -- the vector ALU work of a load segment (address
+// selects of the im2col gather, LDS address arithmetic) is starved beside the partner's MFMAs, so a load segment must be
+// almost free of it: the gather goes through a buffer descriptor (out-of-range offset = zero fill: 3 VALU instructions
+// per piece), every LDS address is one of four per-lane bases + an immediate, waits are counted (s_waitcnt vmcnt(N)
+// through the builtin; the compiler inserts none before a ds_read while LDS-DMA is in flight), and s_setprio made no
+// difference (+-0.5 %).
+//
+// The loader runs ahead of the MFMAs across k-steps AND tiles: phase A of k-step u requests X1 of k-step u + 1, phase B
+// requests X0, W0, W1 of k-step u + 2 -- every piece at least two phases after the last read of the bytes it overwrites
+// -- and each phase retires what the next one reads with ONE counted wait (vmcnt(8): only the eight youngest requests
+// may be outstanding); the barrier after it publishes that to the other waves.  The next tile's first k-steps are
+// therefore in LDS before this tile's epilogue starts.  A segment (a tile, or a piece of one) holds an even number of
+// k-steps, so the LDS buffer of a k-step is a compile-time constant.
+//
+// y3_conv2d_fused_ws adds the balanced split (PpWork below); measured slower inside the network than the partial round
+// it removes (profiles/r03e), so the plan executor uses it only on request.
 #include "common.h"
 #include "conv_common.h"
 #include <type_traits>
