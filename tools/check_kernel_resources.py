@@ -12,7 +12,7 @@ import re
 import sys
 
 GUARDED = ("conv3x3_c32_kernel", "conv3x3s2_c64_kernel", "conv1x1_regw_kernel", "resblock64_kernel", "resblock128_kernel",
-           "conv_pp_kernel")
+           "conv_pp_kernel", "conv_pp_split_kernel")
 
 
 def main(path):

@@ -219,7 +219,7 @@ class _CompiledPlan(object):
                     self._ws_ops += 1
                     self._ws_slab_bytes = max(self._ws_slab_bytes, nb_ws)
                     op["balanced"] = True
-                    op["kernel"] = "conv_pp_kernel"     # (with the workspace the tile choice can differ from y3_conv_kernel_name's)
+                    op["kernel"] = "conv_pp_split_kernel"
 
                     def launch_ws(env, _keep=(d, w, bias)):
                         return fws(dref, x(env), wp, bp, r(env), y(env), zp, ptrs[0], nb_ws, ptrs[1] + k_ws * 1024, env["stream"])
