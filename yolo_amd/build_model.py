@@ -324,8 +324,8 @@ class Network(object):
         # split-K for launches with few output tiles (small batches: latency mode).  Off by default: split sums are
         # added in another order, so results are no longer bit-identical across batch sizes / chunking.
         self.splitk = bool(splitk)
-        # y3_conv2d_fused_ws for the launches that leave a partial round of 256 x 256 tiles: same bits, but measured 4 - 8 %
-        # SLOWER per layer inside the network (profiles/r03e), so off unless asked for (YOLO_AMD_BALANCED=1: A/B)
+        # y3_conv2d_fused_ws for the launches that leave a partial round of 256 x 256 tiles: same bits, but measured 16 - 20 %
+        # SLOWER per layer inside the network (profiles/r03l), so off unless asked for (YOLO_AMD_BALANCED=1: A/B)
         self.balanced = (os.environ.get("YOLO_AMD_BALANCED", "0") == "1") if balanced is None else bool(balanced)
         # residual blocks (1x1 -> 3x3 -> shortcut) as one launch: None = where the planner finds it pays (bf16, large
         # launches), False = never; YOLO_AMD_RESBLOCK=0 for A/B runs.  Same bits either way.

@@ -891,7 +891,7 @@ int launch_igemm(const ConvArgs &a, int n_pad, hipStream_t stream, const HeadDec
 // priced by the measured relative cost of one tile (profiles/r01_layer_report_v3_*: a 192x256 tile costs
 // 0.80 of a 256x256 one, a 128x128 one 0.55 with two of them resident per CU).
 // (A workspace for conv_pp_kernel's balanced split does not change the choice: measured inside the network the split
-// costs more than the partial round it removes -- profiles/r03e -- so it never tips the scale towards the 256 x 256 tile.)
+// costs more than the partial round it removes -- profiles/r03l -- so it never tips the scale towards the 256 x 256 tile.)
 inline int conv_variant(const y3_conv_desc *d, long M) {
     const int bn = d->out_c > 64 ? 128 : (d->out_c > 32 ? 64 : 32);
     if (bn == 64 && d->dtype == Y3_BF16) {

@@ -36,7 +36,7 @@
 // k-steps, so the LDS buffer of a k-step is a compile-time constant.
 //
 // y3_conv2d_fused_ws adds the balanced split: conv_pp_split.hip, a second kernel with this one's loop -- measured slower
-// inside the network than the partial round it removes (profiles/r03e), so the plan executor uses it only on request, and
+// inside the network than the partial round it removes (profiles/r03l), so the plan executor uses it only on request, and
 // kept out of this kernel because its larger tile set-up, placed where it fits the registers (before a phase's fragment
 // reads instead of under their latency), made EVERY launch 8-12 % slower while the two were one kernel (profiles/r03k).
 #include "common.h"

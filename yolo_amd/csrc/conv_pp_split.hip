@@ -4,7 +4,7 @@
 // cut tiles summed in order through fp32 slabs.  A kernel of its own because the larger segment set-up only fits the
 // 256 registers when it runs BEFORE a phase's fragment reads instead of under their latency, and that order costs the
 // plain launches 8-12 % (profiles/r03k).  Launched only with a caller's workspace, i.e. on request: inside the bench
-// network the split measured slower than the partial round it removes (profiles/r03e).
+// network the split measured slower than the partial round it removes (profiles/r03l).
 // Replaces tf.layers.conv2d + batch_normalization + leaky_relu (+ tf.math.add) of build_model.py:151-178,224.
 #include "common.h"
 #include "conv_common.h"
