@@ -404,6 +404,46 @@ def test_conv_balanced_split_after_whole_rounds(B, H, C, O):
     assert np.all(np.abs(outs["plain"] - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
 
 
+PP192_CASES = [
+    # B, H, W, Cin, Cout, ks, stride, residual, leaky, (in_pad, out_pad)
+    (48, 19, 19, 512, 1024, 3, 1, True, True, ((0, 0), (0, 0))),      # the 19x19 residual-stage layer: 364 tiles of 192 pixels, ragged last one
+    (64, 19, 19, 1024, 512, 1, 1, False, True, ((0, 0), (0, 0))),     # its 1x1 bottleneck: 16 k-steps, two channel tiles
+    (10, 38, 38, 512, 1024, 3, 2, False, False, ((0, 0), (0, 0))),    # stride 2, linear
+    (40, 38, 38, 256, 512, 3, 1, True, True, ((256, 0), (0, 512))),   # 602 tiles: several per workgroup; channel slices of wider buffers
+    (1, 13, 13, 128, 256, 3, 1, True, True, ((0, 0), (0, 0))),        # a single ragged tile (169 pixels)
+    (3, 26, 26, 64, 256, 1, 1, True, True, ((0, 0), (8, 8))),         # K = 64: below four k-steps, stays on conv_igemm_kernel
+    (2, 24, 24, 96, 256, 3, 1, False, True, ((0, 0), (0, 0))),        # Cin = 96 (k-steps straddle taps): stays on conv_igemm_kernel
+]
+
+
+@pytest.mark.parametrize("case", PP192_CASES, ids=str)
+def test_conv_pingpong_192_pixel_tile_equals_the_implicit_gemm(case):
+    """conv_pp_kernel<3>: the two-wave-group main loop on 192-pixel tiles (LDS pixel rows as [half][group][48], a pass and a
+    half per half-tile, 7 LDS-DMA instructions per wave and k-step) -- against the oracle, and bit for bit against
+    conv_igemm_kernel's 192 x 256 and 128 x 128 tiles (same sums in the same order), both tile orders."""
+    from yolo_amd import _lib
+    B, H, W, C, O, ks, stride, res, leaky, pads = case
+    rng = np.random.default_rng(B * 1000 + H + C + 1)
+    x = gpu_util.bf16_round(rng.standard_normal((B, H, W, C)).astype(np.float32))
+    k = gpu_util.bf16_round((rng.standard_normal((ks, ks, C, O)) * np.sqrt(2.0 / (ks * ks * C))).astype(np.float32))
+    b = rng.standard_normal(O).astype(np.float32)
+    want = _ref(x, k, b, stride, leaky)
+    r = gpu_util.bf16_round(rng.standard_normal(want.shape).astype(np.float32)) if res else None
+    if res:
+        want = want + r
+    kw = dict(leaky=leaky, residual=r, in_pad=pads[0], out_pad=pads[1])
+    outs = {}
+    with _lib.experimental() as exp:
+        for tile in (704, 192, 128):
+            _lib.check(exp.y3_set_conv_tile(tile))
+            outs[tile] = gpu_util.run_conv(x, k, b, stride, "bf16", **kw)
+        _lib.check(exp.y3_set_conv_tile(704))
+        outs["rev"] = gpu_util.run_conv(x, k, b, stride, "bf16", reverse=True, **kw)
+    assert np.all(np.abs(outs[704] - want) <= 1e-2 * np.maximum(1.0, np.abs(want)))
+    for key in (192, 128, "rev"):
+        np.testing.assert_array_equal(outs[704], outs[key], err_msg=str(key))
+
+
 def test_conv_pingpong_is_what_the_big_layers_run_on():
     """y3_conv_kernel_name: the product library sends the 256 x 256-tile launches with a bf16 output to conv_pp_kernel
     (the fp32 heads keep conv_igemm_kernel's LDS epilogue with the fused decode)."""
@@ -415,10 +455,14 @@ def test_conv_pingpong_is_what_the_big_layers_run_on():
     d.flags = _lib.CONV_LEAKY | _lib.CONV_RESIDUAL
     name = ctypes.create_string_buffer(96)
     _lib.check(lib.y3_conv_kernel_name(ctypes.byref(d), name, 96))
-    assert name.value.decode() == "conv_pp_kernel"
+    assert name.value.decode() == "conv_pp_kernel<4>"
     d.flags = _lib.CONV_OUT_F32
     _lib.check(lib.y3_conv_kernel_name(ctypes.byref(d), name, 96))
     assert name.value.decode().startswith("conv_igemm_kernel<true, 256, 256")
+    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld, d.out_h, d.out_w, d.out_c, d.out_ld, d.res_ld, d.k_pad, d.n_pad = 64, 19, 19, 512, 512, 19, 19, 1024, 1024, 1024, 4608, 1024
+    d.flags = _lib.CONV_LEAKY | _lib.CONV_RESIDUAL
+    _lib.check(lib.y3_conv_kernel_name(ctypes.byref(d), name, 96))
+    assert name.value.decode() == "conv_pp_kernel<3>"           # 19 x 19 at batch 64: 192-pixel tiles, the same main loop
 
 
 @pytest.mark.parametrize("B,H,W,leaky,pads", [(3, 304, 304, True, ((0, 0), (0, 0))), (4, 296, 280, True, ((64, 0), (128, 16))),

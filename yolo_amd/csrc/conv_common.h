@@ -145,7 +145,7 @@ __device__ __forceinline__ void conv_epilogue_regs(const ConvArgs &p, f32x4 (&ac
 // conv_pp.hip: the two-wave-group main loop for the 256 x 256 bf16 tile with the register epilogue; conv_igemm.hip's
 // launcher dispatches to it (same packed weights, same sums in the same order: same bits).  With a.sk_slabs / a.sk_flags
 // set and a launch that would leave a partial round it hands over to conv_pp_split.hip (the balanced split).
-bool y3_conv_pp_ok(const ConvArgs &a, int n_pad);
-int y3_conv_pp_launch(ConvArgs a, int n_pad, long cus, int phase_pct, hipStream_t stream);
+bool y3_conv_pp_ok(const ConvArgs &a, int n_pad, int rows);             // rows: 256 or 192 pixels per tile
+int y3_conv_pp_launch(ConvArgs a, int n_pad, int rows, long cus, int phase_pct, hipStream_t stream);
 long y3_conv_pp_slab_bytes(const ConvArgs &a, int n_pad, long cus);      // workspace the balanced split wants (0 = none)
 int y3_conv_pp_split_launch(ConvArgs a, int n_pad, long cus, hipStream_t stream);

@@ -923,7 +923,12 @@ inline int conv_variant(const y3_conv_desc *d, long M) {
 }
 
 // which launches of the 256 x 256 tile take conv_pp.hip's main loop (y3_conv_pp_ok has the per-launch conditions)
-inline bool conv_pp_applies(int v) { return (v == 256 && g_conv_tile == 0 && g_conv_debug == 0) || (v == 512 && g_conv_tile == 512); }
+// (returns the pixel rows of conv_pp_kernel's tile, 0 = not a launch for it; 512 / 704 = y3_set_conv_tile's codes that force it)
+inline int conv_pp_rows(int v) {
+    if ((v == 256 && g_conv_tile == 0 && g_conv_debug == 0) || (v == 512 && g_conv_tile == 512)) return 256;
+    if ((v == 192 && g_conv_tile == 0 && g_conv_debug == 0) || (v == 704 && g_conv_tile == 704)) return 192;
+    return 0;
+}
 
 inline int bn_for(int out_c) { return out_c > 64 ? 128 : (out_c > 32 ? 64 : 32); }
 
@@ -1095,18 +1100,19 @@ static int conv_launch(const y3_conv_desc *d, const void *in, const void *w, con
     }
     // the 256 x 256 bf16 tile with the register epilogue runs on the ping-pong main loop (conv_pp.hip): same bits
     // (y3_set_conv_tile(256) keeps the one-barrier-per-k-step kernel for A/B runs and the tile-equality tests, 512 forces this one)
-    if (bf16 && splits <= 1 && conv_pp_applies(v) && y3_conv_pp_ok(a, d->n_pad)) {
+    if (bf16 && splits <= 1 && !hd && conv_pp_rows(v) && y3_conv_pp_ok(a, d->n_pad, conv_pp_rows(v))) {
         a.sk_slabs = nullptr;
         a.sk_flags = nullptr;
-        if (pp_slabs != nullptr) {                  // the caller's workspace for the balanced split (y3_conv2d_fused_ws)
+        if (pp_slabs != nullptr && conv_pp_rows(v) == 256) {        // the caller's workspace for the balanced split (y3_conv2d_fused_ws)
             const long need = y3_conv_pp_slab_bytes(a, d->n_pad, conv_cus());
             Y3_REQUIRE(pp_slab_bytes >= need, Y3_E_INVALID, "conv_ws: workspace of %ld bytes, %ld needed", pp_slab_bytes, need);
             Y3_REQUIRE(pp_flags != nullptr && aligned16(pp_slabs) && aligned16(pp_flags), Y3_E_ALIGN, "conv_ws: workspace / flags null or not 16-byte aligned");
             if (need > 0) { a.sk_slabs = (char *)pp_slabs; a.sk_flags = pp_flags; }
         }
-        return y3_conv_pp_launch(a, d->n_pad, conv_cus(), g_conv_phase_pct, stream);
+        return y3_conv_pp_launch(a, d->n_pad, conv_pp_rows(v), conv_cus(), g_conv_phase_pct, stream);
     }
     if (v == 512) v = 256;
+    if (v == 704) v = 192;
     if (bf16) {
         if (v == 257) return launch_ring<true, 256, 128, 2, 2, 128, 3>(a, d->n_pad, stream);
         if (v == 256) return launch_igemm<true, 256, 256, 2, 4, 128>(a, d->n_pad, stream);
@@ -1145,12 +1151,12 @@ extern "C" int y3_conv_workspace_bytes(const y3_conv_desc *d, int64_t *slab_byte
     if (y3_conv_weight_layout(&chk) != 0 || chk.n_pad != d->n_pad || chk.k_pad != d->k_pad) return Y3_OK;
     if (d->dtype != Y3_BF16 || (d->flags & (Y3_CONV_OUT_F32 | Y3_CONV_UPS2X)) || d->out_h <= 0 || d->out_w <= 0) return Y3_OK;
     const long M = (long)d->batch * d->out_h * d->out_w;
-    if (M >= 0x7fffffffL || !conv_pp_applies(conv_variant(d, M))) return Y3_OK;
+    if (M >= 0x7fffffffL || conv_pp_rows(conv_variant(d, M)) != 256) return Y3_OK;
     ConvArgs a{};
     a.flags = CONV_REG_EPILOGUE; a.splits = 1; a.Kpad = d->k_pad; a.Cin = d->in_c; a.M = (int)M;
     a.HoWo = d->out_h * d->out_w; a.H = d->in_h; a.W = d->in_w; a.in_ld = d->in_ld;
     const long ob = M * (long)d->out_ld * 2, rb = M * (long)d->res_ld * 2;
-    if (ob < 0xffff0000L && rb < 0xffff0000L && y3_conv_pp_ok(a, d->n_pad)) *slab_bytes = y3_conv_pp_slab_bytes(a, d->n_pad, conv_cus());
+    if (ob < 0xffff0000L && rb < 0xffff0000L && y3_conv_pp_ok(a, d->n_pad, 256)) *slab_bytes = y3_conv_pp_slab_bytes(a, d->n_pad, conv_cus());
     return Y3_OK;
 }
 
@@ -1368,13 +1374,13 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
         return Y3_OK;
     }
     const int v = conv_variant(d, M);
-    if (d->dtype == Y3_BF16 && conv_pp_applies(v) && !(d->flags & (Y3_CONV_OUT_F32 | Y3_CONV_UPS2X)) && d->out_ld > 0) {
+    if (d->dtype == Y3_BF16 && conv_pp_rows(v) && !(d->flags & (Y3_CONV_OUT_F32 | Y3_CONV_UPS2X)) && d->out_ld > 0) {
         ConvArgs a{};                                   // what conv_launch would hand to y3_conv_pp_ok
         a.flags = CONV_REG_EPILOGUE; a.splits = 1; a.Kpad = d->k_pad; a.Cin = d->in_c; a.M = (int)M;
         a.HoWo = d->out_h * d->out_w; a.H = d->in_h; a.W = d->in_w; a.in_ld = d->in_ld;
         const long ob = M * (long)d->out_ld * 2, rb = M * (long)d->res_ld * 2;
-        if (ob < 0xffff0000L && rb < 0xffff0000L && y3_conv_pp_ok(a, d->n_pad)) {
-            snprintf(buf, (size_t)len, "conv_pp_kernel");
+        if (ob < 0xffff0000L && rb < 0xffff0000L && y3_conv_pp_ok(a, d->n_pad, conv_pp_rows(v))) {
+            snprintf(buf, (size_t)len, "conv_pp_kernel<%d>", conv_pp_rows(v) / 64);
             return Y3_OK;
         }
     }
@@ -1386,7 +1392,7 @@ extern "C" int y3_conv_kernel_name(const y3_conv_desc *d, char *buf, int len) {
     else if (v == 261) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 256, 64, 2, 2", t);
     else if (v == 130 || v == 131) snprintf(buf, (size_t)len, "conv_igemm_ring_kernel<%s, 128, 128, 2, 2", t);
     else if (v == 256 || v == 512) snprintf(buf, (size_t)len, "%s<%s, 256, 256, 2, 4", k, t);
-    else if (v == 192) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
+    else if (v == 192 || v == 704) snprintf(buf, (size_t)len, "%s<%s, 192, 256, 2, 4", k, t);
     else if (v == 128) snprintf(buf, (size_t)len, "%s<%s, 128, 128, 2, 2", k, t);
     else if (v == 64) snprintf(buf, (size_t)len, "%s<%s, 128, 64, 2, 2", k, t);
     else snprintf(buf, (size_t)len, "%s<%s, 128, 32, 4, 1", k, t);
@@ -1414,7 +1420,7 @@ extern "C" int y3_set_conv_phase(int percent) {
 extern "C" int y3_set_conv_tile(int tile) {
     g_conv_debug = tile >> 16;                 // high half: debug bits for timing experiments
     tile &= 0xffff;
-    Y3_REQUIRE(tile == 0 || tile == 512 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 64 || tile == 257 || tile == 258 || tile == 260 || tile == 261, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
+    Y3_REQUIRE(tile == 0 || tile == 512 || tile == 704 || tile == 128 || tile == 129 || tile == 130 || tile == 131 || tile == 192 || tile == 256 || tile == 64 || tile == 257 || tile == 258 || tile == 260 || tile == 261, Y3_E_INVALID, "conv tile %d (0, 128, 192, 256 or 257)", tile);
     g_conv_tile = tile;
     return Y3_OK;
 }

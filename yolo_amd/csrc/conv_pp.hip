@@ -68,8 +68,17 @@ __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rs, unsigned off
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, off, 0, 0, 0);
 }
 
+// MH = 16-pixel row blocks per wave and phase: 4 = the 256-pixel tile (128 pixels per wave group, two halves of 64), 3 = the
+// 192-pixel tile (96 per group, halves of 48) for launches whose tile count fits 192-pixel tiles better (19 x 19 at batch
+// 64: 1.9 rounds instead of 1.4 -> 2).  MH = 3 keeps the pixel rows of an LDS buffer as [half][group][48], so that a
+// half-tile (96 rows) is one run: a loader pass of all 512 threads (64 rows) + half a pass (32 rows) issued by the wave
+// group of the same number as the half -- every wave issues 7 LDS-DMA instructions per k-step (8 at MH = 4), the two
+// groups alternate in who issues the extra one.  Needs Cin % 64 == 0 (a k-step within one tap).
+template <int MH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_pp_kernel(const ConvArgs p) {
+    constexpr int BM = 64 * MH;                     // pixels per tile
+    constexpr int VM_STEADY = MH == 4 ? 8 : 7;      // LDS-DMA instructions a wave may have in flight behind what a phase needs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,8 +104,10 @@ void conv_pp_kernel(const ConvArgs p) {
     const int lrow = tid >> 3;
     const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;       // source chunk (elements) of this LDS slot
     const int tap0 = kc / p.Cin, cin0 = kc - tap0 * p.Cin;
-    int a_base[4];                                  // byte offset of the row's window in the input (< 2 GiB: launcher)
-    unsigned a_nmask[4];                            // bit t set = tap t of the row lies OUTSIDE the picture
+    // this thread's pixel rows: MH = 4: loader passes q = 0..3 (rows 64 q + lrow); MH = 3: [0], [1] = the full pass of half
+    // 0 / 1, [2] = the half pass this wave group issues (half wm)
+    int a_base[MH == 4 ? 4 : 3];                    // byte offset of the row's window in the input (< 2 GiB: launcher)
+    unsigned a_nmask[MH == 4 ? 4 : 3];              // bit t set = tap t of the row lies OUTSIDE the picture
     unsigned w_off[4];
     int tap = 0, cin = 0, tapc = 0, toff = 0;
     int l_tile = blockIdx.x, l_kt = 0, lb = 0, l_m0 = 0;     // wave-uniform: the k-step the loader is on, its LDS buffer
@@ -107,22 +118,27 @@ void conv_pp_kernel(const ConvArgs p) {
     constexpr bool skip_x = false, skip_w = false;
 #endif
 
-    auto l_rows = [&](int h) {                      // im2col set-up of the X rows of half h (loader passes h, h + 2)
+    auto l_row = [&](int slot, int pixel) {
+        const int gm = l_m0 + pixel;
+        long base = 0;
+        unsigned mask = 0;
+        if (gm < p.M) row_setup(p, gm, 2, base, mask);
+        a_base[slot] = (int)base;
+        a_nmask[slot] = ~mask;
+    };
+    auto l_rows = [&](int h) {                      // im2col set-up of the X rows of half h
+        if constexpr (MH == 4) {                    // loader passes h, h + 2: LDS row = pixel
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = h + 2 * j;
-            const int gm = l_m0 + lrow + 64 * q;
-            long base = 0;
-            unsigned mask = 0;
-            if (gm < p.M) row_setup(p, gm, 2, base, mask);
-            a_base[q] = (int)base;
-            a_nmask[q] = ~mask;
+            for (int j = 0; j < 2; ++j) l_row(h + 2 * j, lrow + 64 * (h + 2 * j));
+        } else {                                    // LDS row 96 h + r holds pixel 96 (r / 48) + 48 h + r % 48 (group r / 48)
+            l_row(h, lrow < 48 ? 48 * h + lrow : 96 + 48 * h + (lrow - 48));
+            if (wm == h) l_row(2, 96 + 48 * h + 16 + 8 * wn + (lane >> 3));     // rows 64 + 8 (wave & 3) + lane / 8 of the half
         }
     };
     auto l_tile_begin = [&]() {
         const int bid = xcd_remap(l_tile, total, reverse);
         const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
-        l_m0 = mt * 256;
+        l_m0 = mt * BM;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {               // LDS row 64 q + lrow = [half][wave column][32 channels]
             const int idx = lrow + 64 * (q & 1);
@@ -159,11 +175,20 @@ void conv_pp_kernel(const ConvArgs p) {
     };
     auto stage_x = [&](int h) {                     // three vector instructions per piece besides the DMA itself
         if (!l_live || skip_x) return;
+        if constexpr (MH == 4) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = h + 2 * j;
-            const unsigned out_of_picture = (unsigned)__builtin_amdgcn_sbfe((int)a_nmask[q], tapc, 1);    // 0 or ~0
-            bufdma16(rs_in, (unsigned)(a_base[q] + toff) | out_of_picture, smem + lb * PP_XBUF + q * 8192 + wave * 1024);
+            for (int j = 0; j < 2; ++j) {
+                const int q = h + 2 * j;
+                const unsigned out_of_picture = (unsigned)__builtin_amdgcn_sbfe((int)a_nmask[q], tapc, 1);    // 0 or ~0
+                bufdma16(rs_in, (unsigned)(a_base[q] + toff) | out_of_picture, smem + lb * PP_XBUF + q * 8192 + wave * 1024);
+            }
+        } else {
+            const unsigned oop = (unsigned)__builtin_amdgcn_sbfe((int)a_nmask[h], tapc, 1);
+            bufdma16(rs_in, (unsigned)(a_base[h] + toff) | oop, smem + lb * PP_XBUF + h * (96 * 128) + wave * 1024);
+            if (wm == h) {                          // the half's last 32 rows: 8 per wave of the group with the half's number
+                const unsigned oop2 = (unsigned)__builtin_amdgcn_sbfe((int)a_nmask[2], tapc, 1);
+                bufdma16(rs_in, (unsigned)(a_base[2] + toff) | oop2, smem + lb * PP_XBUF + h * (96 * 128) + 64 * 128 + wn * 1024);
+            }
         }
     };
     auto stage_w = [&](int h) {
@@ -178,7 +203,8 @@ void conv_pp_kernel(const ConvArgs p) {
     // ---- consumer addressing: four per-lane bases, everything else is an immediate ----------------------------------
     const int frow = lane & 15, fq = lane >> 4, fsw = (lane >> 1) & 7;
     const int so0 = ((0 + fq) ^ fsw) * 16, so1 = ((4 + fq) ^ fsw) * 16;
-    const int xb0 = (wm * 128 + frow) * 128 + so0, xb1 = (wm * 128 + frow) * 128 + so1;
+    constexpr int X_GROUP_ROWS = MH == 4 ? 128 : 48, X_HALF_ROWS = MH == 4 ? 64 : 96;    // LDS rows between the groups / the halves
+    const int xb0 = (wm * X_GROUP_ROWS + frow) * 128 + so0, xb1 = (wm * X_GROUP_ROWS + frow) * 128 + so1;
     const int wb0 = PP_W0 + (wn * 32 + frow) * 128 + so0, wb1 = PP_W0 + (wn * 32 + frow) * 128 + so1;
 
     // ---- prologue: k-step 0 complete, k-step 1's X0, W0 and W1 in flight ---------------------------------------------
@@ -197,31 +223,31 @@ void conv_pp_kernel(const ConvArgs p) {
     stage_x(0);
     stage_w(0);
     stage_w(1);
-    __builtin_amdgcn_s_waitcnt(pp_wait_enc(6));
+    __builtin_amdgcn_s_waitcnt(pp_wait_enc(MH == 4 ? 6 : 5));      // (k-step 1's X0, W0, W1: at least 5 instructions)
     __builtin_amdgcn_s_barrier();
 
     for (int c_tile = blockIdx.x; c_tile < total; c_tile += (int)gridDim.x) {
     const int bid = xcd_remap(c_tile, total, reverse);
     const int mt = bid / p.n_tiles, nt = bid - mt * p.n_tiles;
-    const int m0 = mt * 256, n0 = nt * 256;
-    f32x4 acc[4][8];
+    const int m0 = mt * BM, n0 = nt * 256;
+    f32x4 acc[4][2 * MH];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const f32x4 b0 = *(const f32x4 *)(smem + PP_BIAS + (n0 + wn * 64 + ni * 16 + fq * 4) * 4);
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = b0;
+        for (int mi = 0; mi < 2 * MH; ++mi) acc[ni][mi] = b0;
     }
     // One k-step on LDS buffer CB (compile-time, so that the fragment reads need no address arithmetic; the number of
     // k-steps is even: y3_conv_pp_ok): two phases of 32 MFMAs.
     auto kstep = [&](auto CB) {
         constexpr int cb = decltype(CB)::value;
-        bf16x8 xf[4][2], wf[4][2];
+        bf16x8 xf[MH][2], wf[4][2];
         auto read_x = [&](auto XH) {
             constexpr int xh = decltype(XH)::value;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                xf[mi][0] = *(const bf16x8 *)(smem + xb0 + (cb * PP_XBUF + (xh * 64 + mi * 16) * 128));
-                xf[mi][1] = *(const bf16x8 *)(smem + xb1 + (cb * PP_XBUF + (xh * 64 + mi * 16) * 128));
+            for (int mi = 0; mi < MH; ++mi) {
+                xf[mi][0] = *(const bf16x8 *)(smem + xb0 + (cb * PP_XBUF + (xh * X_HALF_ROWS + mi * 16) * 128));
+                xf[mi][1] = *(const bf16x8 *)(smem + xb1 + (cb * PP_XBUF + (xh * X_HALF_ROWS + mi * 16) * 128));
             }
         };
         auto read_w = [&](auto WH) {
@@ -239,9 +265,9 @@ void conv_pp_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[2 * wh + ni][4 * xh + mi] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * wh + ni][ks], xf[mi][ks], acc[2 * wh + ni][4 * xh + mi], 0, 0, 0);
+                    for (int mi = 0; mi < MH; ++mi)
+                        acc[2 * wh + ni][MH * xh + mi] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * wh + ni][ks], xf[mi][ks], acc[2 * wh + ni][MH * xh + mi], 0, 0, 0);
         };
         // group 1 runs half a phase behind group 0: its barrier comes first, group 0's last.  A load segment ends
         // with its own fragment reads retired (lgkmcnt(0) BEFORE the barrier): what a phase has read may be
@@ -270,7 +296,7 @@ void conv_pp_kernel(const ConvArgs p) {
         if (l_kt == 0 && l_live) l_rows(1);         // a new tile's X1 rows (its X0 rows were set up at the last phase B)
         stage_x(1);
         // X1 of this k-step has landed once only the eight youngest requests remain (the last phase B's six, these two)
-        if (l_live) __builtin_amdgcn_s_waitcnt(pp_wait_enc(8));
+        if (l_live) __builtin_amdgcn_s_waitcnt(pp_wait_enc(VM_STEADY));
         else __builtin_amdgcn_s_waitcnt(pp_wait_enc(0));
         seg_mfma();
         mfmas(ic<0>{}, ic<0>{});
@@ -284,7 +310,7 @@ void conv_pp_kernel(const ConvArgs p) {
         stage_w(0);
         stage_w(1);
         // X0, W0, W1 of the next k-step have landed once only the eight youngest remain (its X1, this phase's six)
-        if (l_live) __builtin_amdgcn_s_waitcnt(pp_wait_enc(8));
+        if (l_live) __builtin_amdgcn_s_waitcnt(pp_wait_enc(VM_STEADY));
         else __builtin_amdgcn_s_waitcnt(pp_wait_enc(0));
         seg_mfma();
         mfmas(ic<1>{}, ic<1>{});
@@ -301,31 +327,32 @@ void conv_pp_kernel(const ConvArgs p) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) sacc += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
+            for (int mi = 0; mi < 2 * MH; ++mi) sacc += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
         if (sacc == 123.456f) *(float *)p.out = sacc;
         continue;
     }
 #endif
-    u32x4 rv[8][2];
-    if (p.flags & Y3_CONV_RESIDUAL) conv_epilogue_regs<128, 64, 8, 4, 0, 1>(p, acc, rv, m0, n0, lane, wm, wn);
-    else conv_epilogue_regs<128, 64, 8, 4, 0, 0>(p, acc, rv, m0, n0, lane, wm, wn);
+    u32x4 rv[2 * MH][2];
+    if (p.flags & Y3_CONV_RESIDUAL) conv_epilogue_regs<32 * MH, 64, 2 * MH, 4, 0, 1>(p, acc, rv, m0, n0, lane, wm, wn);
+    else conv_epilogue_regs<32 * MH, 64, 2 * MH, 4, 0, 0>(p, acc, rv, m0, n0, lane, wm, wn);
     }
 }
 
 }  // namespace
 
-bool y3_conv_pp_ok(const ConvArgs &a, int n_pad) {
+bool y3_conv_pp_ok(const ConvArgs &a, int n_pad, int rows) {
     if (!(a.flags & CONV_REG_EPILOGUE) || a.splits > 1) return false;
     if (n_pad % 256 != 0 || n_pad > PP_MAX_COUT || a.Kpad % 128 != 0 || a.Kpad / 64 < 4) return false;     // an even number of k-steps
     if (a.Cin % 8 != 0) return false;
+    if (rows == 192 && a.Cin % 64 != 0) return false;                  // (the 192-pixel tile's loader: a k-step within one tap)
     const long in_bytes = ((long)(a.M / a.HoWo) * a.H * a.W + 2L * a.W + 2) * a.in_ld * 2;    // (+ the halo the base offsets may point at)
     if (in_bytes >= 0x7fff0000L || (long)n_pad * a.Kpad * 2 >= 0x7fff0000L) return false;
-    return true;
+    return rows == 256 || rows == 192;
 }
 
-int y3_conv_pp_launch(ConvArgs a, int n_pad, long cus, int phase_pct, hipStream_t stream) {
+int y3_conv_pp_launch(ConvArgs a, int n_pad, int rows, long cus, int phase_pct, hipStream_t stream) {
     // with a caller's workspace, the launches that would leave a partial round take the balanced split (conv_pp_split.hip)
-    if (a.sk_slabs != nullptr && y3_conv_pp_slab_bytes(a, n_pad, cus) > 0) return y3_conv_pp_split_launch(a, n_pad, cus, stream);
+    if (rows == 256 && a.sk_slabs != nullptr && y3_conv_pp_slab_bytes(a, n_pad, cus) > 0) return y3_conv_pp_split_launch(a, n_pad, cus, stream);
     a.sk_slabs = nullptr;
     a.n_tiles = n_pad / 256;
     // extents of the LDS-DMA buffer descriptors: anything past them reads as zero (the loader relies on that)
@@ -335,13 +362,14 @@ int y3_conv_pp_launch(ConvArgs a, int n_pad, long cus, int phase_pct, hipStream_
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (attr_dev != dev) {
-        if (hipFuncSetAttribute((const void *)conv_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)conv_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) {
             y3_set_error("conv_pp: cannot reserve %d bytes of LDS", PP_LDS);
             return Y3_E_LAUNCH;
         }
         attr_dev = dev;
     }
-    const long m_tiles = ((long)a.M + 255) / 256;
+    const long m_tiles = ((long)a.M + rows - 1) / rows;
     const long nblk = m_tiles * a.n_tiles;
     if (nblk <= 0 || nblk > 0x7fffffffL) { y3_set_error("conv_pp: grid of %ld blocks", nblk); return Y3_E_INVALID; }
     a.total_tiles = (int)nblk;
@@ -352,10 +380,11 @@ int y3_conv_pp_launch(ConvArgs a, int n_pad, long cus, int phase_pct, hipStream_
     a.delay_from = 0;
     const long rem = nblk % grid;
     if (grid == cus && nblk >= 4 * cus && rem != 0 && phase_pct > 0) {
-        const double tile_us = 2.0 * 256 * 256 * (double)a.Kpad / 5.4e6;          // at ~5.4 TFLOP/s per CU
+        const double tile_us = 2.0 * rows * 256 * (double)a.Kpad / 5.4e6;         // at ~5.4 TFLOP/s per CU
         a.delay_ticks = (unsigned)(tile_us * phase_pct);                          // 100 ticks per us, percent
         a.delay_from = (int)rem;
     }
-    hipLaunchKernelGGL(conv_pp_kernel, dim3((unsigned)grid), dim3(512), PP_LDS, stream, a);
+    if (rows == 256) hipLaunchKernelGGL(conv_pp_kernel<4>, dim3((unsigned)grid), dim3(512), PP_LDS, stream, a);
+    else hipLaunchKernelGGL(conv_pp_kernel<3>, dim3((unsigned)grid), dim3(512), PP_LDS, stream, a);
     return y3_check_launch("conv_pp");
 }
