@@ -16,7 +16,8 @@ extern "C" {
 #endif
 
 /* Force the implicit-GEMM tile of y3_conv2d_fused: low 16 bits = tile (0 = heuristic, 128, 129, 130, 131, 192, 256,
- * 64, 257, 258, 260, 261: see the table at the top of csrc/conv_igemm.hip); high 16 bits = debug bits (2 no
+ * 64, 257, 258, 260, 261: see the table at the top of csrc/conv_igemm.hip; 512 / 704 = conv_pp_kernel's 256- / 192-pixel
+ * tile wherever it applies, while a forced 256 / 192 keeps conv_igemm_kernel); high 16 bits = debug bits (2 no
  * interleave, 4 ring-pipelined main loop, 64 LDS epilogue, 128 one workgroup per tile; 1/8/16/32 are TIMING
  * experiments that skip loads or the epilogue and produce garbage results). */
 int y3_set_conv_tile(int tile);
