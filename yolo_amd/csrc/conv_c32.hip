@@ -26,9 +26,6 @@ constexpr int C32_PITCH = 96;                      // bytes between patch pixels
 constexpr int C32_SLOTS = C32_NPOS * 6;            // 16-byte slots of a patch (4 data + 2 pad per pixel)
 constexpr int C32_BUF = (C32_SLOTS + 511) / 512 * 512 * 16;   // bytes per patch buffer (whole loader passes)
 constexpr int C32_NT = 512;
-#ifndef C32_SPREAD
-#define C32_SPREAD 0
-#endif
 constexpr int C32_KPAD = 320;                      // packed weight row: 9 * 32 = 288, padded to a multiple of 64
 
 struct C32Args {
@@ -126,7 +123,7 @@ void conv3x3_c32_kernel(const C32Args p) {
         const bool more = next < p.total_tiles;
         if (more) {                                // the next tile's patch and shortcut operand travel under this tile's MFMAs
             tile_coords(next, nb, nh0, nw0);
-            if (!C32_SPREAD) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * C32_BUF);
+            issue_x(nb, nh0, nw0, smem + (cur ^ 1) * C32_BUF);
             if (has_res) res_load(rvn, nb, nh0, nw0);
         }
         f32x4 acc[2][4];
@@ -144,13 +141,8 @@ void conv3x3_c32_kernel(const C32Args p) {
                 for (int ni = 0; ni < 2; ++ni)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ni], xf, acc[ni][mi], 0, 0, 0);
             }
-            // (C32_SPREAD) one loader pass after each of the first taps: an LDS-DMA instruction holds its wave for
-            // 60-180 cycles, which the SIMD's other wave fills with MFMAs here and cannot at the top of the tile
-            if (C32_SPREAD && t < C32_BUF / (C32_NT * 16)) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * C32_BUF, t, t + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            // (measured and not kept: one loader pass after each of the first taps instead of all at the top of the tile --
+            // what pays in resblock64_kernel made this kernel slower)
         }
         // ---- epilogue: leaky, + shortcut (fp32), one bf16 rounding, 16-byte stores; lanes past the picture are dropped ----
 #pragma unroll

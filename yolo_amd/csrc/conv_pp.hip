@@ -53,10 +53,6 @@ constexpr int PP_BIAS = 4 * PP_XBUF;                // fp32 bias of every output
 constexpr int PP_MAX_COUT = 2048;
 constexpr int PP_LDS = PP_BIAS + PP_MAX_COUT * 4;
 
-#ifndef PP_PRIO
-#define PP_PRIO 0       // s_setprio 1 around the MFMA clusters (1): starves the partner wave's loader arithmetic
-#endif
-
 constexpr int pp_wait_enc(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }    // s_waitcnt vmcnt(v) only
 
 template <int N> using ic = std::integral_constant<int, N>;
@@ -281,10 +277,8 @@ void conv_pp_kernel(const ConvArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (PP_PRIO) __builtin_amdgcn_s_setprio(1);
         };
         auto seg_end = [&]() {
-            if (PP_PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (wm == 0) __builtin_amdgcn_s_barrier();
         };

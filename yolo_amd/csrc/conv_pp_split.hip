@@ -21,14 +21,8 @@ constexpr int PP_MAX_COUT = 2048;
 constexpr int PP_DEC = PP_BIAS + PP_MAX_COUT * 4;   // balanced split: 1 = the predecessor's partial sums are there, 2 = recompute
 constexpr int PP_LDS = PP_DEC + 16;
 constexpr int PP_SLAB = 256 * 256 * 4;              // bytes of one workgroup's fp32 partial sums (balanced split)
-#ifndef PP_SLAB_AUX
-#define PP_SLAB_AUX 16                              // cache policy of the slab accesses: sc1 (agent scope, written through)
-#endif
+constexpr int PP_SLAB_AUX = 16;                     // cache policy of the slab accesses: sc1 (agent scope, written through; + nt: no gain)
 constexpr int PP_SPIN_LIMIT = 1 << 17;              // polls of the predecessor's flag before giving up and recomputing
-
-#ifndef PP_ABLATE
-#define PP_ABLATE 0
-#endif
 
 constexpr int pp_wait_enc(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }    // s_waitcnt vmcnt(v) only
 
@@ -158,11 +152,6 @@ void conv_pp_split_kernel(const ConvArgs p) {
     int tap = 0, cin = 0, tapc = 0, toff = 0;
     int l_seg = 0, l_kt = 0, l_kt1 = 0, lb = 0, l_m0 = 0;    // wave-uniform: the k-step the loader is on, its LDS buffer
     bool l_live = wk.nseg > 0, l_newtile = false;
-#if PP_ABLATE          // timing experiments of an A/B build (tools/ab_build.sh abl -DPP_ABLATE=1; garbage results)
-    const bool skip_x = p.flags & (1 << 29), skip_w = p.flags & (1 << 28);
-#else
-    constexpr bool skip_x = false, skip_w = false;
-#endif
 
     auto l_rows = [&](int h) {                      // im2col set-up of the X rows of half h (loader passes h, h + 2)
 #pragma unroll
@@ -234,7 +223,7 @@ void conv_pp_split_kernel(const ConvArgs p) {
         if (l_live) l_kstep_begin();
     };
     auto stage_x = [&](int h) {                     // three vector instructions per piece besides the DMA itself
-        if (!l_live || skip_x) return;
+        if (!l_live) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q = h + 2 * j;
@@ -243,7 +232,7 @@ void conv_pp_split_kernel(const ConvArgs p) {
         }
     };
     auto stage_w = [&](int h) {
-        if (!l_live || skip_w) return;
+        if (!l_live) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q = 2 * h + j;
@@ -403,17 +392,6 @@ void conv_pp_split_kernel(const ConvArgs p) {
         if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         continue;
     }
-#if PP_ABLATE
-    if (p.flags & (1 << 27)) {                      // timing experiment: no epilogue (one store keeps the accumulators live)
-        float sacc = 0.f;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) sacc += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
-        if (sacc == 123.456f) *(float *)p.out = sacc;
-        continue;
-    }
-#endif
     u32x4 rv[8][2];
     if (p.flags & Y3_CONV_RESIDUAL) conv_epilogue_regs<128, 64, 8, 4, 0, 1>(p, acc, rv, m0, n0, lane, wm, wn);
     else conv_epilogue_regs<128, 64, 8, 4, 0, 0>(p, acc, rv, m0, n0, lane, wm, wn);
@@ -463,9 +441,6 @@ int y3_conv_pp_split_launch(ConvArgs a, int n_pad, long cus, hipStream_t stream)
     // workgroups de-phase by themselves, every one starts with a different share of a cut tile.
     const long q = nblk >> 3, G = grid >> 3;
     a.lock_rounds = (int)((2 * q - G) / (2 * G));
-#ifdef PP_NO_LOCK_ROUNDS
-    a.lock_rounds = 0;                              // A/B build: everything dealt as one contiguous range per workgroup
-#endif
     a.delay_ticks = 0;
     a.delay_from = 0;
     hipLaunchKernelGGL(conv_pp_split_kernel, dim3((unsigned)grid), dim3(512), PP_LDS, stream, a);

@@ -31,31 +31,6 @@
 #include "common.h"
 #include <type_traits>
 
-#ifndef Y3_RB_PREFETCH
-#define Y3_RB_PREFETCH 1    // touch the next tile's x and this tile's shortcut lines during phase 2 (L2 prefetch)
-#endif
-
-#ifndef Y3_RB_STAMPS
-#define Y3_RB_STAMPS 0      // diagnostic build only (gpurun_ab): per-segment s_memtime sums of every workgroup's wave 0
-#endif
-#if Y3_RB_STAMPS
-__device__ unsigned long long rb_stamps[256][8];
-extern "C" int y3_resblock_stamps(unsigned long long *host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rb_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -3;
-}
-#define RB_STAMP(k)                                                                                   \
-    do {                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        unsigned long long t_;                                                                        \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        seg[k] += t_ - tprev;                                                                         \
-        tprev = t_;                                                                                   \
-    } while (0)
-#else
-#define RB_STAMP(k) do {} while (0)
-#endif
-
 namespace {
 
 constexpr int RB_TW = 19;                          // tile width in pixels (608/8 = 76 = 4 * 19, 152 = 8 * 19, 304 = 16 * 19)
@@ -181,19 +156,13 @@ void resblock_kernel(const ResArgs p) {
         tile_coords(tile, b, h0, w0, th);
         issue_x(b, h0, w0, th);
     }
-#if Y3_RB_STAMPS
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-#endif
     for (; tile < p.total_tiles; tile += gridDim.x) {
         // ---- phase 1: y = leaky(W1 x + b1) on the tile + halo -------------------------------------------------------
         constexpr int NMF1 = NI1 * MI1;
         bias1_load();
         w1_load();
-        RB_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's x (requested before the last tile's stores) and W1 have landed
         lds_barrier();                             // ... in every wave
-        RB_STAMP(1);                               // 1: wait for W1 + x, barrier
         f32x4 acc1[NI1][MI1];
 #pragma unroll
         for (int ni = 0; ni < NI1; ++ni)
@@ -227,7 +196,6 @@ void resblock_kernel(const ResArgs p) {
                 }
             }
         }
-        RB_STAMP(2);                               // 2: phase 1 MFMA loop
         lds_barrier();                             // every wave is done with x: the y image overlays it
 #pragma unroll
         for (int mi = 0; mi < MI1; ++mi) {
@@ -247,7 +215,6 @@ void resblock_kernel(const ResArgs p) {
             }
         }
 
-        RB_STAMP(3);                               // 3: barrier + y write
         // ---- phase 2: 3x3 over the y image ---------------------------------------------------------------------------
         // pixel of (row block, lane): blocks 0 .. th-1 are the first 16 columns of a tile row (consecutive positions: the
         // bank-conflict-free case), the blocks after them collect columns 16..18 of all rows
@@ -282,7 +249,7 @@ void resblock_kernel(const ResArgs p) {
         // unused) the lines the tile boundary will need: the next tile's x and this tile's shortcut operand.
         int nb = 0, nh0 = 0, nw0 = 0, nth = 0;
         const bool have_next = tile + (int)gridDim.x < p.total_tiles;
-        if (Y3_RB_PREFETCH && have_next) tile_coords(tile + (int)gridDim.x, nb, nh0, nw0, nth);
+        if (have_next) tile_coords(tile + (int)gridDim.x, nb, nh0, nw0, nth);
         // The loaded dword's register must stay allocated until the load has landed: the compiler does not know that an
         // asm load writes its output later, so `pfd` is kept alive up to the next s_waitcnt vmcnt(0) (pf_landed()).
         unsigned pfd = 0;
@@ -291,7 +258,7 @@ void resblock_kernel(const ResArgs p) {
         };
         auto pf_landed = [&]() { asm volatile("" ::"v"(pfd) : "memory"); };
         auto prefetch_step = [&](int kt) {
-            if constexpr (Y3_RB_PREFETCH != 0) {
+            {
                 constexpr int X0 = 2, XN = (RB_NPOS * (C * 2 / 128) + 511) / 512;        // k-steps that touch the next x
                 constexpr int R0 = NK2 - 4, RN = (256 * (C * 2 / 128) + 511) / 512;      // ... this tile's shortcut lines
                 constexpr int LPP = C * 2 / 128;                                         // lines per pixel
@@ -353,7 +320,6 @@ void resblock_kernel(const ResArgs p) {
             for (int kt = 0; kt + 1 < NK2; ++kt) kstep2(kt, std::true_type{});
         }
         kstep2(NK2 - 1, std::false_type{});
-        RB_STAMP(4);                               // 4: phase 2
         lds_barrier();                             // the y image and W2's buffers are no longer read: LDS is free for the next x
 
         // ---- epilogue: leaky, + x (shortcut), one bf16 rounding; the next tile's x is requested before the stores ----
@@ -406,7 +372,6 @@ void resblock_kernel(const ResArgs p) {
         for (int mi = 0; mi < MI; ++mi)
             ooff[mi] = pix[mi] != 0xffffffffu ? (pix[mi] * (unsigned)p.out_ld + (unsigned)nl) * 2u : OOB;
         pf_landed();                               // (the shortcut loads above are younger than any touch and have been waited for)
-        RB_STAMP(5);                               // 5: barrier, shortcut operand loads, epilogue arithmetic
         __builtin_amdgcn_sched_barrier(0);
         const int next = tile + (int)gridDim.x;
         if (next < p.total_tiles) {                // the next tile's x is requested ahead of this tile's stores
@@ -421,14 +386,7 @@ void resblock_kernel(const ResArgs p) {
                 for (int pr = 0; pr < NP2; ++pr)
                     __builtin_amdgcn_raw_buffer_store_b128(o[mi][pr], rs_out, ooff[mi], pr * 64, 0);
         }
-        RB_STAMP(6);                               // 6: next x issued, stores issued
     }
-#if Y3_RB_STAMPS
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) rb_stamps[blockIdx.x & 255][k] = seg[k];
-    }
-#endif
 }
 
 template <int CM, int WM, int WN>

@@ -31,12 +31,6 @@ constexpr int R6_XBUF = (R6_XSLOTS + R6_NT - 1) / R6_NT * R6_NT * 16;   // 57,34
 constexpr int R6_NBLK = (R6_NPOS + 15) / 16;       // 21 row blocks of 16 patch pixels in phase 1
 constexpr int R6_YBUF = R6_NPOS * R6_YP;           // 31,104
 constexpr int R6_LDS = 2 * R6_XBUF + R6_YBUF;      // 145,792
-#ifndef R6_FASTPATH
-#define R6_FASTPATH 1                              // interior tiles: loader offsets from registers, no bounds arithmetic
-#endif
-#ifndef R6_SPREAD
-#define R6_SPREAD 1                                // loader passes among phase 2's first taps (0: all at the top of the tile): -2 %
-#endif
 constexpr int R6_K2PAD = 320;                      // packed 3x3 weight row: 9 * 32 = 288 padded to a multiple of 64
 static_assert(R6_NBLK * 16 * R6_XP <= R6_XBUF, "phase 1 reads whole row blocks of the patch buffer");
 static_assert(R6_LDS <= 160 * 1024, "LDS budget");
@@ -96,7 +90,6 @@ void resblock64_kernel(const R6Args p) {
     // A tile whose patch lies inside the picture (4 of 5 at 304 x 304) takes per-lane offsets computed once per launch:
     // two VALU instructions per loader pass instead of twenty (this kernel issues 1.4 VALU cycles per MFMA cycle).
     constexpr int NPASS = R6_XBUF / (R6_NT * 16);
-#if R6_FASTPATH
     int rel[NPASS];                                // byte offset of this lane's slot from the patch's first pixel, -1 = none
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -105,9 +98,7 @@ void resblock64_kernel(const R6Args p) {
         const int pr = (pos * 3641) >> 16, pc = pos - pr * R6_P;
         rel[i] = (pos < R6_NPOS && c < 8) ? (pr * p.W + pc) * p.x_ld * 2 + c * 16 : -1;
     }
-#endif
     auto issue_x = [&](int b, int h0, int w0, char *buf, int i0 = 0, int i1 = NPASS) {
-#if R6_FASTPATH
         if (h0 >= 1 && w0 >= 1 && h0 + R6_T + 1 <= p.H && w0 + R6_T + 1 <= p.W) {      // (wave-uniform)
             const char *base = p.x + (long)((b * p.H + h0 - 1) * p.W + w0 - 1) * p.x_ld * 2;
 #pragma unroll
@@ -115,7 +106,6 @@ void resblock64_kernel(const R6Args p) {
                 if (rel[i] >= 0) glds16(base + rel[i], buf + i * (R6_NT * 16) + wave * 1024);
             return;
         }
-#endif
         int tidv = tid;
         asm volatile("" : "+v"(tidv));             // (per-tile arithmetic on purpose: see conv_resblock128.hip)
 #pragma unroll
@@ -154,7 +144,6 @@ void resblock64_kernel(const R6Args p) {
         const bool more = next < p.total_tiles;
         if (more) {                                // the next tile's patch travels under this tile's MFMAs
             tile_coords(next, nb, nh0, nw0);
-            if (!R6_SPREAD) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R6_XBUF);
         }
         // ---- phase 1: y = leaky(W1 x + b1) on the patch: row blocks wave, wave + 8, wave + 16 ----------------------------
         const bool interior = h0 >= 1 && w0 >= 1 && h0 + R6_T + 1 <= p.H && w0 + R6_T + 1 <= p.W;
@@ -175,7 +164,7 @@ void resblock64_kernel(const R6Args p) {
                     for (int ni = 0; ni < 2; ++ni)
                         a1[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[kb][ni], xf[kb], a1[ni], 0, 0, 0);
                 bool in = true;                    // outside the picture: the 3x3's zero padding
-                if (!(R6_FASTPATH && interior)) {
+                if (!interior) {
                     const int pr = (pos * 3641) >> 16, pc = pos - pr * R6_P;
                     const int h = h0 - 1 + pr, w = w0 - 1 + pc;
                     in = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
@@ -209,9 +198,9 @@ void resblock64_kernel(const R6Args p) {
                 for (int ni = 0; ni < 2; ++ni)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ni], yf, acc[ni][mi], 0, 0, 0);
             }
-            // (R6_SPREAD) one loader pass after each of the first taps: an LDS-DMA instruction holds its wave for 60-180
-            // cycles, which the SIMD's other wave fills with MFMAs here and cannot at the top of the tile
-            if (R6_SPREAD && t < R6_XBUF / (R6_NT * 16)) {
+            // one loader pass after each of the first taps (all of them at the top of the tile: +2 %): an LDS-DMA instruction
+            // holds its wave for 60-180 cycles, which the SIMD's other wave fills with MFMAs here and cannot up there
+            if (t < R6_XBUF / (R6_NT * 16)) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) issue_x(nb, nh0, nw0, smem + (cur ^ 1) * R6_XBUF, t, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
