@@ -373,7 +373,7 @@ int y3_conv_pp_launch(ConvArgs a, int n_pad, int rows, long cus, int phase_pct, 
     a.delay_ticks = 0;
     a.delay_from = 0;
     const long rem = nblk % grid;
-    if (grid == cus && nblk >= 4 * cus && rem != 0 && phase_pct > 0) {
+    if (grid == cus && nblk >= 2 * cus && rem != 0 && phase_pct > 0) {
         const double tile_us = 2.0 * rows * 256 * (double)a.Kpad / 5.4e6;         // at ~5.4 TFLOP/s per CU
         a.delay_ticks = (unsigned)(tile_us * phase_pct);                          // 100 ticks per us, percent
         a.delay_from = (int)rem;
